@@ -1,0 +1,332 @@
+"""CPU restatement (numpy + SciPy) of the reference's per-protein kinetic models.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Each function cites the reference
+file:line it follows.  The integrator arithmetic of the reference lives in a third-party
+dependency, ``scipy.integrate.odeint`` (ODEPACK LSODA; reference pins scipy 1.15.2 in
+poetry.lock:1838, this image has 1.15.3) -- the oracle calls the very same routine, with
+the same defaults, on a numpy restatement of the reference's right-hand sides.
+
+Model ids used everywhere in this repo: 0 = distmod, 1 = succmod, 2 = randmod.
+State layout (all models): y = [R, P, X_1 .. X_m]; m = n_sites (dist/succ) or 2**n - 1 (rand).
+Parameter layout: theta = [A, B, C, D, S_1..S_n, D_1..D_m]   (reference unpack_params).
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+from scipy.integrate import odeint
+from scipy.linalg import expm
+
+DIST, SUCC, RAND = 0, 1, 2
+MODEL_NAMES = {DIST: "distmod", SUCC: "succmod", RAND: "randmod"}
+MODEL_IDS = {v: k for k, v in MODEL_NAMES.items()}
+
+#: reference time grid, config/constants.py:56-62
+TIME_POINTS = np.array([0.0, 0.5, 0.75, 1.0, 2.0, 4.0, 8.0, 16.0, 30.0, 60.0,
+                        120.0, 240.0, 480.0, 960.0])
+
+
+def n_states(model: int, n_sites: int) -> int:
+    return 2 + (n_sites if model != RAND else (1 << n_sites) - 1)
+
+
+def n_params(model: int, n_sites: int) -> int:
+    return 4 + n_sites + (n_sites if model != RAND else (1 << n_sites) - 1)
+
+
+def unpack_params(model: int, params, n_sites: int):
+    """distmod.py:68-91, succmod.py:94-112, randmod.py:88-119."""
+    p = np.asarray(params, dtype=float)
+    m = n_sites if model != RAND else (1 << n_sites) - 1
+    return p[0], p[1], p[2], p[3], p[4:4 + n_sites].copy(), p[4 + n_sites:4 + n_sites + m].copy()
+
+
+# --------------------------------------------------------------------------- RHS
+def rhs_dist(y, t, A, B, C, D, S, Dr):
+    """models/distmod.py:7-65 (ode_core)."""
+    n = S.shape[0]
+    R, P = y[0], y[1]
+    dy = np.empty_like(y)
+    dy[0] = A - B * R
+    sum_S = 0.0
+    for i in range(n):
+        sum_S += S[i]
+    sum_P = 0.0
+    for i in range(n):
+        sum_P += y[2 + i]
+    dy[1] = C * R - (D + sum_S) * P + sum_P
+    for i in range(n):
+        dy[2 + i] = S[i] * P - (1.0 + Dr[i]) * y[2 + i]
+    return dy
+
+
+def rhs_succ(y, t, A, B, C, D, S, Dr):
+    """models/succmod.py:9-90 (ode_core), incl. the n == 1 branch (:59-63)."""
+    n = S.shape[0]
+    R, P = y[0], y[1]
+    dy = np.empty_like(y)
+    dy[0] = A - B * R
+    dP = C * R - D * P
+    if n > 0:
+        dP -= S[0] * P
+        dP += y[2]
+    dy[1] = dP
+    for i in range(n):
+        if n == 1:
+            dy[2] = S[0] * P - (1 + Dr[0]) * y[2]
+        elif i == 0:
+            dy[2] = S[0] * P - (1 + S[1] + Dr[0]) * y[2] + y[3]
+        elif i < n - 1:
+            dy[2 + i] = S[i] * y[1 + i] - (1 + S[i + 1] + Dr[i]) * y[2 + i] + y[3 + i]
+        else:
+            dy[2 + i] = S[i] * y[1 + i] - (1 + Dr[i]) * y[2 + i]
+    return dy
+
+
+def rand_tables(n: int):
+    """models/randmod.py:9-85 (_precompute_indices); int64 tables, 1-based state masks."""
+    m = (1 << n) - 1
+    mono_idx = np.array([(1 << j) - 1 for j in range(n)], dtype=np.int64)
+    forward = -np.ones((m, n), dtype=np.int64)
+    drop = -np.ones((m, n), dtype=np.int64)
+    fcounts = np.zeros(m, dtype=np.int64)
+    dcounts = np.zeros(m, dtype=np.int64)
+    for state in range(1, m + 1):
+        fi = di = 0
+        for j in range(n):
+            if not (state & (1 << j)):
+                forward[state - 1, fi] = state | (1 << j)
+                fcounts[state - 1] += 1
+                fi += 1
+            else:
+                drop[state - 1, di] = state & ~(1 << j)
+                dcounts[state - 1] += 1
+                di += 1
+    return mono_idx, forward, drop, fcounts, dcounts
+
+
+def rhs_rand(y, t, A, B, C, D, n, S, Ddeg, tables=None):
+    """models/randmod.py:122-247 (ode_system), verbatim control flow.
+
+    Quirk kept on purpose (randmod.py:201): the rate of the forward transition
+    state -> tgt uses S[j] with j = log2(lowest set bit of the TARGET mask)."""
+    mono_idx, forward, drop, fcounts, dcounts = tables if tables is not None else rand_tables(n)
+    m = (1 << n) - 1
+    R, P = y[0], y[1]
+    dR = A - B * R
+    dP = C * R - D * P
+    dX = np.zeros(m)
+    for k in range(n):
+        rate = S[k] * P
+        dX[mono_idx[k]] += rate
+        dP -= rate
+    for state in range(1, m + 1):
+        xi = y[1 + state]
+        base = state - 1
+        for k in range(fcounts[base]):
+            tgt = forward[base, k] - 1
+            j = int(math.log2((tgt + 1) & -(tgt + 1)))
+            rate = S[j] * xi
+            dX[tgt] += rate
+            dX[base] -= rate
+        for k in range(dcounts[base]):
+            lower = drop[base, k]
+            rate = xi
+            if lower == 0:
+                dP += rate
+            else:
+                dX[lower - 1] += rate
+            dX[base] -= rate
+        dX[base] -= Ddeg[base] * xi
+    out = np.empty(2 + m)
+    out[0] = dR
+    out[1] = dP
+    out[2:] = dX
+    return out
+
+
+def rhs(model: int, y, t, params, n_sites: int):
+    A, B, C, D, S, Dr = unpack_params(model, params, n_sites)
+    y = np.asarray(y, dtype=float)
+    if model == DIST:
+        return rhs_dist(y, t, A, B, C, D, S, Dr)
+    if model == SUCC:
+        return rhs_succ(y, t, A, B, C, D, S, Dr)
+    return rhs_rand(y, t, A, B, C, D, n_sites, S, Dr)
+
+
+# ---------------------------------------------------------------- LTI form M y + b
+def lti_matrix(model: int, params, n_sites: int):
+    """Analytic Jacobian M (constant in y, t) and forcing b with dy/dt = M y + b.
+
+    Derived from the three RHS above; the reference never
+    forms it (LSODA finite-differences).  Built column-by-column from the RHS itself so it
+    cannot drift from it: M[:, j] = rhs(e_j) - rhs(0), b = rhs(0) (exact: the RHS is affine)."""
+    S_ = n_states(model, n_sites)
+    b = rhs(model, np.zeros(S_), 0.0, params, n_sites)
+    M = np.empty((S_, S_))
+    for j in range(S_):
+        e = np.zeros(S_)
+        e[j] = 1.0
+        M[:, j] = rhs(model, e, 0.0, params, n_sites) - b
+    return M, b
+
+
+def jacobian_analytic(model: int, params, n_sites: int):
+    """Closed-form Jacobian, written independently of `lti_matrix` (row-major J[i, j] = d f_i / d y_j)."""
+    A, B, C, D, S, Dr = unpack_params(model, params, n_sites)
+    n = n_sites
+    S_ = n_states(model, n)
+    J = np.zeros((S_, S_))
+    J[0, 0] = -B
+    J[1, 0] = C
+    if model == DIST:
+        J[1, 1] = -(D + S.sum())
+        for i in range(n):
+            J[1, 2 + i] = 1.0
+            J[2 + i, 1] = S[i]
+            J[2 + i, 2 + i] = -(1.0 + Dr[i])
+    elif model == SUCC:
+        J[1, 1] = -D
+        if n > 0:
+            J[1, 1] -= S[0]
+            J[1, 2] = 1.0
+        for i in range(n):
+            J[2 + i, 1 + i] = S[i]
+            J[2 + i, 2 + i] = -(1.0 + Dr[i] + (S[i + 1] if i < n - 1 else 0.0))
+            if i < n - 1:
+                J[2 + i, 3 + i] = 1.0
+    else:
+        J[1, 1] = -(D + S.sum())
+        m = (1 << n) - 1
+        for mask in range(1, m + 1):
+            row = 1 + mask
+            lsb = (mask & -mask).bit_length() - 1
+            out_rate = 0.0
+            for j in range(n):
+                bit = 1 << j
+                if mask & bit:
+                    src = mask ^ bit
+                    # inflow into `mask` from src (or from P): coefficient S[lsb(mask)] (quirk)
+                    J[row, 1 + src if src else 1] += S[lsb]
+                    # this state dephosphorylates bit j at unit rate
+                    lower = mask ^ bit
+                    J[1 + lower if lower else 1, row] += 1.0
+                    out_rate += 1.0
+                else:
+                    tgt = mask | bit
+                    out_rate += S[((tgt & -tgt).bit_length() - 1)]
+            J[row, row] -= out_rate + Dr[mask - 1]
+    return J
+
+
+# ----------------------------------------------------------------------- solve
+def _odeint(model, params, y0, n_sites, t, **kw):
+    A, B, C, D, S, Dr = unpack_params(model, params, n_sites)
+    if model == DIST:
+        return odeint(rhs_dist, y0, t, args=(A, B, C, D, S, Dr), **kw)
+    if model == SUCC:
+        return odeint(rhs_succ, y0, t, args=(A, B, C, D, S, Dr), **kw)
+    tabs = rand_tables(n_sites)
+    return odeint(rhs_rand, y0, t, args=(A, B, C, D, n_sites, S, Dr, tabs), **kw)
+
+
+def flatten_observables(model: int, sol: np.ndarray, n_sites: int) -> np.ndarray:
+    """distmod.py:125-134, succmod.py:143-152, randmod.py:284-305: [R(t5..), P(t0..), sites site-major].
+    randmod keeps only the first n_sites phospho columns (randmod.py:298-299)."""
+    R_f = sol[5:, 0]
+    P_f = sol[:, 1]
+    if model == RAND:
+        X_f = sol[:, 2:2 + n_sites].T
+    else:
+        X_f = sol[:, 2:].T
+    return np.concatenate((R_f.ravel(), P_f.ravel(), X_f.ravel()))
+
+
+def solve_ode(model: int, params, init_cond, n_sites: int, t, normalize: bool = False, **odeint_kw):
+    """models/{distmod.py:93-134, succmod.py:114-152, randmod.py:249-305}: odeint at SciPy defaults
+    (rtol = atol = 1.49012e-8, no Dfun) -> clip >= 0 -> optional / y0 -> flat."""
+    t = np.atleast_1d(np.asarray(t, dtype=float))
+    y0 = np.asarray(init_cond, dtype=float)
+    sol = np.clip(np.asarray(_odeint(model, params, y0, n_sites, t, **odeint_kw)), 0, None)
+    if normalize:
+        sol *= (1.0 / y0)[None, :]
+    return sol, flatten_observables(model, sol, n_sites)
+
+
+def solve_tight(model: int, params, init_cond, n_sites: int, t):
+    """Same SciPy odeint, same RHS, rtol = atol = 1e-13, mxstep = 500000 (SURVEY.md section 7 'y_ref_tight').
+    NOT clipped."""
+    t = np.atleast_1d(np.asarray(t, dtype=float))
+    return np.asarray(_odeint(model, params, np.asarray(init_cond, float), n_sites, t,
+                              rtol=1e-13, atol=1e-13, mxstep=500000))
+
+
+def solve_exact_lti(model: int, params, init_cond, n_sites: int, t):
+    """Third, integrator-free truth for the (linear time-invariant) per-protein models:
+    z = [y; 1], dz/dt = [[M, b], [0, 0]] z, stepped interval by interval with scipy.linalg.expm."""
+    t = np.atleast_1d(np.asarray(t, dtype=float))
+    M, b = lti_matrix(model, params, n_sites)
+    S_ = M.shape[0]
+    Aug = np.zeros((S_ + 1, S_ + 1))
+    Aug[:S_, :S_] = M
+    Aug[:S_, S_] = b
+    z = np.concatenate((np.asarray(init_cond, float), [1.0]))
+    out = np.empty((t.size, S_))
+    out[0] = z[:S_]
+    for k in range(1, t.size):
+        z = expm(Aug * (t[k] - t[k - 1])) @ z
+        out[k] = z[:S_]
+    return out
+
+
+# --------------------------------------------------------------------- reductions
+def compute_Y(solution: np.ndarray, n_sites: int, metric: str = "total_signal") -> float:
+    """sensitivity/analysis.py:90-176 (_compute_Y) with Y_METRIC as an argument."""
+    sol = np.asarray(solution, dtype=float)
+    n_t = sol.shape[0]
+    length = 2 * n_t + n_t * n_sites
+    sub = sol[:, :2 + n_sites]
+    total = float(sub[:, 0].sum() + sub[:, 1].sum() + sub[:, 2:].sum())
+    if metric == "total_signal":
+        return total
+    if metric == "mean_activity":
+        return total / length
+    if metric == "variance":
+        mean = total / length
+        return float(((sub - mean) ** 2).sum() / length)
+    if metric == "dynamics":
+        return float((np.diff(sub, axis=0) ** 2).sum())
+    if metric == "l2_norm":
+        return float(math.sqrt((sub ** 2).sum()))
+    raise ValueError("Unknown Y_METRIC")
+
+
+METRICS = ("total_signal", "mean_activity", "variance", "dynamics", "l2_norm")
+
+
+def score_fit(params, target, prediction, alpha=1.0, beta=1.0, gamma=1.0, delta=1.0, mu=1.0):
+    """config/config.py:176-226."""
+    params = np.asarray(params, float)
+    target = np.asarray(target, float)
+    prediction = np.asarray(prediction, float)
+    residual = np.abs(target - prediction) / target.size
+    mse = np.sum(residual ** 2)
+    rmse = np.sqrt(np.mean(residual ** 2))
+    mae = np.mean(residual)
+    variance = np.var(residual)
+    l2 = np.linalg.norm(params, ord=2) / len(params)
+    return delta * mse + alpha * rmse + beta * mae + gamma * variance + mu * l2
+
+
+def compute_bound(value: float, perturbation: float = 0.5):
+    """sensitivity/analysis.py:20-35."""
+    if abs(value) < 1e-6:
+        return [0.0, 0.1]
+    return [max(0.0, value * (1 - perturbation)), value * (1 + perturbation)]
+
+
+def band_error(y, y_ref, rtol=1e-6, atol=1e-8) -> float:
+    """max |y - y_ref| / (atol + rtol |y_ref|)  -- the parity gate of BASELINE.json (pass <= 1)."""
+    y = np.asarray(y); y_ref = np.asarray(y_ref)
+    return float(np.max(np.abs(y - y_ref) / (atol + rtol * np.abs(y_ref))))
