@@ -1,0 +1,134 @@
+/* phoskin.h -- C ABI of libphoskin_hip.so: the MI355X (gfx950) batched stiff-ODE engine for
+ * PhosKinTime's per-protein parameter-estimation hot path.
+ *
+ * The reference (bibymaths/phoskintime) has no FFI: the seam is a set of plain Python callables
+ * (SURVEY.md section 8b).  Every entry point below names the reference callable(s) it replaces.
+ * Signatures use only plain pointers and sizes (no torch / numpy types).  Unless a function name
+ * ends in `_host`, every array pointer is a DEVICE pointer (HBM) and the call is asynchronous on
+ * the context's stream; `_host` variants take host pointers, stage through HBM and synchronise.
+ *
+ * Conventions
+ *   model      0 = distmod (models/distmod.py), 1 = succmod (models/succmod.py), 2 = randmod (models/randmod.py)
+ *   state      y = [R, P, X_1..X_m], m = n_sites (dist/succ) or 2^n_sites - 1 (rand); S = 2 + m   (<= 64)
+ *   theta      [A, B, C, D, S_1..S_n, D_1..D_m], P = 4 + n + m      (reference unpack_params, distmod.py:68-91,
+ *              succmod.py:94-112, randmod.py:88-119); batched as a row-major [B, P] f64 matrix
+ *   return     0 = ok; < 0 = argument / runtime error (see pk_last_error); never throws or aborts.
+ *   status[b]  per-replica bit flags: PK_ST_NONFINITE | PK_ST_MAXSTEPS | PK_ST_HMIN.  A flagged replica's
+ *              remaining output rows are NaN (the reference only warns: odeint returns garbage and callers
+ *              test np.isfinite, e.g. global_model/optproblem.py:125-133).
+ */
+#ifndef PHOSKIN_H
+#define PHOSKIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_VERSION 100
+
+enum { PK_MODEL_DIST = 0, PK_MODEL_SUCC = 1, PK_MODEL_RAND = 2 };
+
+/* Integrators.  RODAS4 is the default and the one the parity gate is stated for. */
+enum {
+  PK_METHOD_RODAS4 = 0, /* adaptive 6-stage L-stable Rosenbrock 4(3) (Hairer-Wanner RODAS), analytic Jacobian, 1 LU / step */
+  PK_METHOD_BDF2   = 1, /* variable-step BDF2 (BDF1 start), analytic Jacobian, LU per step-size change (BASELINE config 3) */
+  PK_METHOD_RK4    = 2  /* classical explicit RK4, fixed step h <= rk4_h (BASELINE config 2); stability-bound when stiff */
+};
+
+/* Linear solver for the implicit stage equations (g I - J) x = r. */
+enum {
+  PK_LINSOLVE_AUTO       = 0, /* structured where the model has one, else dense */
+  PK_LINSOLVE_DENSE      = 1, /* dense in-register LU, one matrix row per lane, cross-lane broadcasts (any model) */
+  PK_LINSOLVE_STRUCTURED = 2  /* arrow (distmod) / tridiagonal (succmod) elimination; randmod falls back to dense */
+};
+
+/* Scalar Morris outputs, sensitivity/analysis.py:90-176 (_compute_Y; Y_METRIC, config/constants.py:104). */
+enum {
+  PK_METRIC_TOTAL_SIGNAL = 0, PK_METRIC_MEAN_ACTIVITY = 1, PK_METRIC_VARIANCE = 2,
+  PK_METRIC_DYNAMICS = 3, PK_METRIC_L2_NORM = 4
+};
+
+enum { PK_ST_OK = 0, PK_ST_NONFINITE = 1, PK_ST_MAXSTEPS = 2, PK_ST_HMIN = 4 };
+
+enum {
+  PK_OK = 0, PK_ERR_ARG = -1, PK_ERR_UNSUPPORTED = -2, PK_ERR_HIP = -3, PK_ERR_NOMEM = -4
+};
+
+typedef struct pk_solver_opts {
+  int32_t method;       /* PK_METHOD_*                                                        */
+  int32_t linsolve;     /* PK_LINSOLVE_*                                                      */
+  double  rtol, atol;   /* local error tolerances (max-norm); defaults 1e-7 / 1e-9            */
+  double  h0;           /* first step; 0 = automatic                                          */
+  double  rk4_h;        /* RK4 only: largest fixed step (each output interval is split evenly) */
+  int32_t max_steps;    /* per replica, accepted + rejected; default 100000                   */
+  int32_t clip_nonneg;  /* np.clip(sol, 0, None) as in distmod.py:112-113 (default 1)         */
+  int32_t normalize;    /* NORMALIZE_MODEL_OUTPUT: sol *= 1 / y0 (distmod.py:116-122)         */
+  int32_t reserved;
+} pk_solver_opts;
+
+typedef struct pk_ctx pk_ctx;
+
+int         pk_version(void);
+/* One context per GPU / per thread.  Owns a HIP stream and a small workspace; nothing else. */
+pk_ctx*     pk_create(int device_id);
+void        pk_destroy(pk_ctx*);
+const char* pk_last_error(pk_ctx*);            /* valid until the next call on this context */
+/* Launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's default
+ * stream).  pk_use_own_stream switches back to the context's private non-blocking stream. */
+int         pk_set_stream(pk_ctx*, void* hip_stream);
+int         pk_use_own_stream(pk_ctx*);
+int         pk_synchronize(pk_ctx*);
+void        pk_default_opts(pk_solver_opts*);
+
+/* Shapes (pure host arithmetic, usable without a GPU). */
+int pk_protein_n_states(int model, int n_sites);           /* S, or PK_ERR_* */
+int pk_protein_n_params(int model, int n_sites);           /* P */
+int pk_protein_flat_len(int model, int n_sites, int T);    /* (T-5) + T + n_sites*T  (distmod.py:125-134) */
+
+/* Replaces, for a whole batch of parameter vectors, models.solve_ode(params, init_cond, num_psites, t)
+ *   -> (sol, flat)   [models/__init__.py:12; distmod.py:93-134, succmod.py:114-152, randmod.py:249-305]
+ * and, fused behind it, sensitivity.analysis._compute_Y (sensitivity/analysis.py:90-176).
+ *   theta [B,P]; y0 [S] (shared) or [B,S]; t [T] with t[0] the initial time, strictly increasing;
+ *   sol [B,T,S] | NULL; flat [B,F] | NULL; metric [B] | NULL; status [B] | NULL; n_steps [B,2] | NULL
+ *   (accepted, rejected).  sol is clipped / normalised per opts exactly like the reference's return value. */
+int pk_solve_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
+                           const double* theta, const double* y0, int y0_is_batched,
+                           const double* t, int T, const pk_solver_opts* opts,
+                           double* sol, double* flat, double* metric, int metric_id,
+                           int32_t* status, int32_t* n_steps);
+
+/* Replaces models.{distmod,succmod}.ode_core / models.randmod.ode_system (distmod.py:7-65, succmod.py:9-90,
+ * randmod.py:122-247) evaluated for a batch: y [B,S] -> dydt [B,S]. */
+int pk_rhs_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
+                         const double* theta, const double* y, double* dydt);
+
+/* Analytic Jacobian d f_i / d y_j, row-major J [B,S,S] (the reference has none for this path: LSODA
+ * finite-differences ode_core; row-major as global_model/simulate.py:75 col_deriv=False). */
+int pk_jacobian_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
+                              const double* theta, double* J);
+
+/* Host-pointer conveniences (stage through HBM, synchronise before returning). */
+int pk_solve_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
+                                const double* theta, const double* y0, int y0_is_batched,
+                                const double* t, int T, const pk_solver_opts* opts,
+                                double* sol, double* flat, double* metric, int metric_id,
+                                int32_t* status, int32_t* n_steps);
+int pk_rhs_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
+                              const double* theta, const double* y, double* dydt);
+int pk_jacobian_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
+                                   const double* theta, double* J);
+
+/* Timing hook for bench.py: runs `iters` back-to-back launches of pk_solve_protein_batch on the context's
+ * stream between two hipEvents and returns the mean kernel time per launch in milliseconds (< 0 on error). */
+double pk_time_solve_protein_batch(pk_ctx*, int iters, int model, int n_sites, int64_t B,
+                                   const double* theta, const double* y0, int y0_is_batched,
+                                   const double* t, int T, const pk_solver_opts* opts,
+                                   double* sol, double* flat, double* metric, int metric_id,
+                                   int32_t* status, int32_t* n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHOSKIN_H */

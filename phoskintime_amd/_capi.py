@@ -1,0 +1,142 @@
+"""ctypes binding of libphoskin_hip.so (include/phoskin.h).  Thin: argument marshalling and error mapping only.
+
+The library is the product's only compute path.  If it is missing or cannot be loaded this module raises
+``PhoskinLibraryError`` -- there is deliberately NO CPU fallback (the CPU restatement under ``oracle/`` is test
+infrastructure and is never imported from here)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libphoskin_hip.so"
+
+DIST, SUCC, RAND = 0, 1, 2
+MODEL_IDS = {"distmod": DIST, "succmod": SUCC, "randmod": RAND}
+MODEL_NAMES = {v: k for k, v in MODEL_IDS.items()}
+METHOD_RODAS4, METHOD_BDF2, METHOD_RK4 = 0, 1, 2
+METHODS = {"rodas4": METHOD_RODAS4, "bdf2": METHOD_BDF2, "rk4": METHOD_RK4}
+LINSOLVE_AUTO, LINSOLVE_DENSE, LINSOLVE_STRUCTURED = 0, 1, 2
+LINSOLVES = {"auto": LINSOLVE_AUTO, "dense": LINSOLVE_DENSE, "structured": LINSOLVE_STRUCTURED}
+METRICS = {"total_signal": 0, "mean_activity": 1, "variance": 2, "dynamics": 3, "l2_norm": 4}
+ST_NONFINITE, ST_MAXSTEPS, ST_HMIN = 1, 2, 4
+
+
+class PhoskinLibraryError(RuntimeError):
+    pass
+
+
+class PhoskinError(RuntimeError):
+    pass
+
+
+class SolverOpts(C.Structure):
+    """Mirror of ``pk_solver_opts`` (include/phoskin.h)."""
+    _fields_ = [("method", C.c_int32), ("linsolve", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double),
+                ("h0", C.c_double), ("rk4_h", C.c_double), ("max_steps", C.c_int32), ("clip_nonneg", C.c_int32),
+                ("normalize", C.c_int32), ("reserved", C.c_int32)]
+
+
+#: every symbol include/phoskin.h declares (tests/test_capi_symbols.py checks the header against this list)
+SYMBOLS = (
+    "pk_version", "pk_create", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts",
+    "pk_protein_n_states", "pk_protein_n_params", "pk_protein_flat_len",
+    "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch",
+    "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
+    "pk_time_solve_protein_batch",
+)
+
+_lib = None
+
+
+def load():
+    """Load libphoskin_hip.so (once) and declare the signatures.  Raises PhoskinLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise PhoskinLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    except OSError as e:  # pragma: no cover
+        raise PhoskinLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    optp = C.POINTER(SolverOpts)
+    lib.pk_version.restype = i32
+    lib.pk_create.restype = vp; lib.pk_create.argtypes = [i32]
+    lib.pk_destroy.restype = None; lib.pk_destroy.argtypes = [vp]
+    lib.pk_last_error.restype = C.c_char_p; lib.pk_last_error.argtypes = [vp]
+    lib.pk_set_stream.restype = i32; lib.pk_set_stream.argtypes = [vp, vp]
+    lib.pk_use_own_stream.restype = i32; lib.pk_use_own_stream.argtypes = [vp]
+    lib.pk_synchronize.restype = i32; lib.pk_synchronize.argtypes = [vp]
+    lib.pk_default_opts.restype = None; lib.pk_default_opts.argtypes = [optp]
+    for f in ("pk_protein_n_states", "pk_protein_n_params"):
+        getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [i32, i32]
+    lib.pk_protein_flat_len.restype = i32; lib.pk_protein_flat_len.argtypes = [i32, i32, i32]
+    solve_args = [vp, i32, i32, i64, vp, vp, i32, vp, i32, optp, vp, vp, vp, i32, vp, vp]
+    for f in ("pk_solve_protein_batch", "pk_solve_protein_batch_host"):
+        getattr(lib, f).restype = i32; getattr(lib, f).argtypes = solve_args
+    for f in ("pk_rhs_protein_batch", "pk_rhs_protein_batch_host"):
+        getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, i32, i32, i64, vp, vp, vp]
+    for f in ("pk_jacobian_protein_batch", "pk_jacobian_protein_batch_host"):
+        getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, i32, i32, i64, vp, vp]
+    lib.pk_time_solve_protein_batch.restype = dbl
+    lib.pk_time_solve_protein_batch.argtypes = [vp, i32] + solve_args[1:]
+    _lib = lib
+    return lib
+
+
+def default_opts(**kw) -> SolverOpts:
+    o = SolverOpts()
+    load().pk_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if v is None:
+            continue
+        if k == "method" and isinstance(v, str):
+            v = METHODS[v]
+        if k == "linsolve" and isinstance(v, str):
+            v = LINSOLVES[v]
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    """One ``pk_ctx`` (one GPU).  Not thread-safe; create one per thread / per rank."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        self.device = int(device)
+        self._h = self.lib.pk_create(self.device)
+        if not self._h:
+            raise PhoskinError(f"pk_create({device}) failed: no usable HIP device (is a GPU visible?)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.pk_last_error(self._h)
+            raise PhoskinError(f"libphoskin_hip error {rc}: {msg.decode() if msg else ''}")
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.pk_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def synchronize(self):
+        self.check(self.lib.pk_synchronize(self._h))
+
+    @property
+    def handle(self):
+        return self._h

@@ -1,0 +1,300 @@
+// pk_capi.hip -- the C ABI of libphoskin_hip.so (include/phoskin.h): argument checking, launch geometry,
+// context / stream management and the host-pointer convenience variants.  No kernels here (pk_solve_kernel.hpp).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/phoskin.h"
+#include "pk_launch.hpp"
+
+struct pk_ctx {
+  int device;
+  hipStream_t own_stream;
+  hipStream_t stream;
+  std::string err;
+  hipEvent_t ev0, ev1;
+};
+
+namespace {
+
+int fail(pk_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define PK_HIP(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return fail(ctx, PK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int group_width(int S) { return S <= 8 ? 8 : S <= 16 ? 16 : S <= 32 ? 32 : S <= 64 ? 64 : 0; }
+
+int check_model(pk_ctx* c, int model, int n_sites) {
+  if (model < 0 || model > 2) return fail(c, PK_ERR_ARG, "model must be 0 (dist), 1 (succ) or 2 (rand)");
+  if (n_sites < 1) return fail(c, PK_ERR_ARG, "n_sites must be >= 1");
+  if (model == PK_MODEL_RAND && n_sites > 5) return fail(c, PK_ERR_UNSUPPORTED, "randmod: n_sites <= 5 (S = 2^n + 1 <= 64 lanes)");
+  if (pk::n_states(model, n_sites) > 64) return fail(c, PK_ERR_UNSUPPORTED, "S = n_sites + 2 must be <= 64 (one lane per state)");
+  return PK_OK;
+}
+
+
+int gidx(int G) { return G == 8 ? 0 : G == 16 ? 1 : G == 32 ? 2 : 3; }
+#define PK_ROW(base, M) {pk::base##M##_g8, pk::base##M##_g16, pk::base##M##_g32, pk::base##M##_g64}
+const pk::SolveLauncher kSolve[3][4] = {PK_ROW(launch_solve_m, 0), PK_ROW(launch_solve_m, 1), PK_ROW(launch_solve_m, 2)};
+const pk::RhsLauncher kRhs[3][4] = {PK_ROW(launch_rhs_m, 0), PK_ROW(launch_rhs_m, 1), PK_ROW(launch_rhs_m, 2)};
+const pk::JacLauncher kJac[3][4] = {PK_ROW(launch_jac_m, 0), PK_ROW(launch_jac_m, 1), PK_ROW(launch_jac_m, 2)};
+#undef PK_ROW
+
+}  // namespace
+
+extern "C" {
+
+int pk_version(void) { return PK_VERSION; }
+
+void pk_default_opts(pk_solver_opts* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->method = PK_METHOD_RODAS4;
+  o->linsolve = PK_LINSOLVE_AUTO;
+  o->rtol = 1e-7;
+  o->atol = 1e-9;
+  o->h0 = 0.0;
+  o->rk4_h = 1e-3;
+  o->max_steps = 100000;
+  o->clip_nonneg = 1;
+  o->normalize = 0;
+}
+
+int pk_protein_n_states(int model, int n_sites) {
+  if (model < 0 || model > 2 || n_sites < 1 || (model == PK_MODEL_RAND && n_sites > 20)) return PK_ERR_ARG;
+  return pk::n_states(model, n_sites);
+}
+int pk_protein_n_params(int model, int n_sites) {
+  if (model < 0 || model > 2 || n_sites < 1 || (model == PK_MODEL_RAND && n_sites > 20)) return PK_ERR_ARG;
+  return pk::n_params(model, n_sites);
+}
+int pk_protein_flat_len(int model, int n_sites, int T) {
+  if (model < 0 || model > 2 || n_sites < 1 || T < 1) return PK_ERR_ARG;
+  return (T > 5 ? T - 5 : 0) + T + n_sites * T;
+}
+
+pk_ctx* pk_create(int device_id) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return nullptr;
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  pk_ctx* c = new pk_ctx();
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  c->stream = c->own_stream;
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return nullptr; }
+  return c;
+}
+
+void pk_destroy(pk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* pk_last_error(pk_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int pk_set_stream(pk_ctx* c, void* s) {
+  if (!c) return PK_ERR_ARG;
+  c->stream = (hipStream_t)s;
+  return PK_OK;
+}
+
+int pk_use_own_stream(pk_ctx* c) {
+  if (!c) return PK_ERR_ARG;
+  c->stream = c->own_stream;
+  return PK_OK;
+}
+
+int pk_synchronize(pk_ctx* c) {
+  if (!c) return PK_ERR_ARG;
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return PK_OK;
+}
+
+int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y0,
+                           int y0_is_batched, const double* t, int T, const pk_solver_opts* opts_in, double* sol,
+                           double* flat, double* metric, int metric_id, int32_t* status, int32_t* n_steps) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (T < 1) return fail(c, PK_ERR_ARG, "T must be >= 1");
+  if (B == 0) return PK_OK;
+  if (!theta || !y0 || !t) return fail(c, PK_ERR_ARG, "theta, y0 and t must be non-null");
+  if (metric && (metric_id < 0 || metric_id > 4)) return fail(c, PK_ERR_ARG, "unknown metric_id");
+  pk_solver_opts o;
+  if (opts_in) o = *opts_in; else pk_default_opts(&o);
+  if (o.method < 0 || o.method > 2) return fail(c, PK_ERR_ARG, "unknown method");
+  if (o.method != PK_METHOD_RK4 && !(o.rtol > 0.0 && o.atol >= 0.0)) return fail(c, PK_ERR_ARG, "rtol must be > 0 and atol >= 0");
+  if (o.method == PK_METHOD_RK4 && !(o.rk4_h > 0.0)) return fail(c, PK_ERR_ARG, "rk4_h must be > 0");
+  if (o.max_steps <= 0) o.max_steps = 100000;
+
+  pk::SolveArgs a;
+  a.theta = theta; a.y0 = y0; a.t = t; a.sol = sol; a.flat = flat; a.metric = metric; a.status = status; a.n_steps = n_steps;
+  a.B = B; a.n_sites = n_sites; a.S = pk::n_states(model, n_sites); a.P = pk::n_params(model, n_sites); a.T = T;
+  a.F = pk_protein_flat_len(model, n_sites, T); a.n_obs = n_sites; a.y0_batched = y0_is_batched ? 1 : 0; a.metric_id = metric_id;
+  a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.rk4_h = o.rk4_h; a.max_steps = o.max_steps; a.clip = o.clip_nonneg; a.normalize = o.normalize;
+
+  const int G = group_width(a.S);
+  const long long rpb = 256 / G;
+  const long long nblk = (B + rpb - 1) / rpb;
+  if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+  const bool structured = (o.linsolve != PK_LINSOLVE_DENSE) && (model != PK_MODEL_RAND);
+  PK_HIP(c, hipSetDevice(c->device));
+  dim3 grid((unsigned)nblk);
+  kSolve[model][gidx(G)](a, o.method, structured, grid, c->stream);
+  PK_HIP(c, hipGetLastError());
+  return PK_OK;
+}
+
+int pk_rhs_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y, double* dydt) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (B == 0) return PK_OK;
+  if (!theta || !y || !dydt) return fail(c, PK_ERR_ARG, "null pointer");
+  const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), G = group_width(S);
+  const long long rpb = 256 / G, nblk = (B + rpb - 1) / rpb;
+  if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+  PK_HIP(c, hipSetDevice(c->device));
+  dim3 grid((unsigned)nblk);
+  kRhs[model][gidx(G)](theta, y, dydt, (long long)B, n_sites, S, P, grid, c->stream);
+  PK_HIP(c, hipGetLastError());
+  return PK_OK;
+}
+
+int pk_jacobian_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, double* J) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (B == 0) return PK_OK;
+  if (!theta || !J) return fail(c, PK_ERR_ARG, "null pointer");
+  const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), G = group_width(S);
+  const long long rpb = 256 / G, nblk = (B + rpb - 1) / rpb;
+  if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+  PK_HIP(c, hipSetDevice(c->device));
+  dim3 grid((unsigned)nblk);
+  kJac[model][gidx(G)](theta, J, (long long)B, n_sites, S, P, grid, c->stream);
+  PK_HIP(c, hipGetLastError());
+  return PK_OK;
+}
+
+// ------------------------------------------------------------------------------- host-pointer variants
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
+};
+}  // namespace
+
+int pk_solve_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y0,
+                                int y0_is_batched, const double* t, int T, const pk_solver_opts* opts, double* sol,
+                                double* flat, double* metric, int metric_id, int32_t* status, int32_t* n_steps) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0 || T < 1) return fail(c, PK_ERR_ARG, "B must be >= 0 and T >= 1");
+  if (B == 0) return PK_OK;
+  if (!theta || !y0 || !t) return fail(c, PK_ERR_ARG, "theta, y0 and t must be non-null");
+  const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), F = pk_protein_flat_len(model, n_sites, T);
+  PK_HIP(c, hipSetDevice(c->device));
+  DevBuf d_th, d_y0, d_t, d_sol, d_flat, d_met, d_st, d_ns;
+  const size_t ny0 = (y0_is_batched ? (size_t)B : 1) * S;
+  PK_HIP(c, d_th.alloc((size_t)B * P * 8));
+  PK_HIP(c, d_y0.alloc(ny0 * 8));
+  PK_HIP(c, d_t.alloc((size_t)T * 8));
+  if (sol) PK_HIP(c, d_sol.alloc((size_t)B * T * S * 8));
+  if (flat) PK_HIP(c, d_flat.alloc((size_t)B * F * 8));
+  if (metric) PK_HIP(c, d_met.alloc((size_t)B * 8));
+  if (status) PK_HIP(c, d_st.alloc((size_t)B * 4));
+  if (n_steps) PK_HIP(c, d_ns.alloc((size_t)B * 8));
+  PK_HIP(c, hipMemcpyAsync(d_th.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(d_y0.p, y0, ny0 * 8, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(d_t.p, t, (size_t)T * 8, hipMemcpyHostToDevice, c->stream));
+  rc = pk_solve_protein_batch(c, model, n_sites, B, (const double*)d_th.p, (const double*)d_y0.p, y0_is_batched,
+                              (const double*)d_t.p, T, opts, (double*)d_sol.p, (double*)d_flat.p, (double*)d_met.p,
+                              metric_id, (int32_t*)d_st.p, (int32_t*)d_ns.p);
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+  if (sol) PK_HIP(c, hipMemcpyAsync(sol, d_sol.p, (size_t)B * T * S * 8, hipMemcpyDeviceToHost, c->stream));
+  if (flat) PK_HIP(c, hipMemcpyAsync(flat, d_flat.p, (size_t)B * F * 8, hipMemcpyDeviceToHost, c->stream));
+  if (metric) PK_HIP(c, hipMemcpyAsync(metric, d_met.p, (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
+  if (status) PK_HIP(c, hipMemcpyAsync(status, d_st.p, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_steps) PK_HIP(c, hipMemcpyAsync(n_steps, d_ns.p, (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return PK_OK;
+}
+
+int pk_rhs_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y, double* dydt) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (B == 0) return PK_OK;
+  if (!theta || !y || !dydt) return fail(c, PK_ERR_ARG, "null pointer");
+  const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites);
+  PK_HIP(c, hipSetDevice(c->device));
+  DevBuf d_th, d_y, d_f;
+  PK_HIP(c, d_th.alloc((size_t)B * P * 8));
+  PK_HIP(c, d_y.alloc((size_t)B * S * 8));
+  PK_HIP(c, d_f.alloc((size_t)B * S * 8));
+  PK_HIP(c, hipMemcpyAsync(d_th.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(d_y.p, y, (size_t)B * S * 8, hipMemcpyHostToDevice, c->stream));
+  rc = pk_rhs_protein_batch(c, model, n_sites, B, (const double*)d_th.p, (const double*)d_y.p, (double*)d_f.p);
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+  PK_HIP(c, hipMemcpyAsync(dydt, d_f.p, (size_t)B * S * 8, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return PK_OK;
+}
+
+int pk_jacobian_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, double* J) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (B == 0) return PK_OK;
+  if (!theta || !J) return fail(c, PK_ERR_ARG, "null pointer");
+  const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites);
+  PK_HIP(c, hipSetDevice(c->device));
+  DevBuf d_th, d_J;
+  PK_HIP(c, d_th.alloc((size_t)B * P * 8));
+  PK_HIP(c, d_J.alloc((size_t)B * S * S * 8));
+  PK_HIP(c, hipMemcpyAsync(d_th.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, c->stream));
+  rc = pk_jacobian_protein_batch(c, model, n_sites, B, (const double*)d_th.p, (double*)d_J.p);
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+  PK_HIP(c, hipMemcpyAsync(J, d_J.p, (size_t)B * S * S * 8, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return PK_OK;
+}
+
+double pk_time_solve_protein_batch(pk_ctx* c, int iters, int model, int n_sites, int64_t B, const double* theta,
+                                   const double* y0, int y0_is_batched, const double* t, int T,
+                                   const pk_solver_opts* opts, double* sol, double* flat, double* metric, int metric_id,
+                                   int32_t* status, int32_t* n_steps) {
+  if (!c || iters < 1) return -1.0;
+  if (hipSetDevice(c->device) != hipSuccess) return -1.0;
+  if (hipEventRecord(c->ev0, c->stream) != hipSuccess) return -1.0;
+  for (int i = 0; i < iters; ++i) {
+    int rc = pk_solve_protein_batch(c, model, n_sites, B, theta, y0, y0_is_batched, t, T, opts, sol, flat, metric, metric_id, status, n_steps);
+    if (rc) return (double)rc;
+  }
+  if (hipEventRecord(c->ev1, c->stream) != hipSuccess) return -1.0;
+  if (hipEventSynchronize(c->ev1) != hipSuccess) { c->err = "hipEventSynchronize failed"; return -1.0; }
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+  return (double)ms / iters;
+}
+
+}  // extern "C"

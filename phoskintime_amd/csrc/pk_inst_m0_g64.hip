@@ -1,0 +1,3 @@
+#define PK_INST_MODEL 0
+#define PK_INST_G 64
+#include "pk_inst.inc"

@@ -1,0 +1,3 @@
+#define PK_INST_MODEL 1
+#define PK_INST_G 32
+#include "pk_inst.inc"

@@ -1,0 +1,131 @@
+// pk_linsolve.hpp -- solvers for the implicit stage systems  (g I - J) x = r,  one replica per lane group.
+//
+//   Dense<G>            any model: W row-per-lane in VGPRs, LU by cross-lane broadcast (pk_wave.hpp)
+//   Arrow<G>  (DIST)    J is an arrow matrix: eliminate the site rows, one group reduction per solve
+//   Tridiag<G> (SUCC)   J is tridiagonal: parallel cyclic reduction, log2(G) neighbour exchanges per solve
+#pragma once
+#include "pk_models.hpp"
+
+namespace pk {
+
+// 1/x to full double precision from v_rcp_f64 + two Newton steps (x normal, non-zero)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+template <int MODEL, int G>
+struct DenseSolver {
+  double a[G];
+  double dinv;
+  __device__ __forceinline__ void factor(const RowCoef& c, const double g, const int S, const int row, const int lane) {
+    fill_w_row<MODEL, G>(a, c, g, S, row);
+    dinv = 1.0;
+    static_for<G>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const double piv = bcast<G, k>(a[k]);
+      const double rp = fast_rcp(piv);
+      if (row == k) dinv = rp;
+      if constexpr (k + 1 < G) {
+        const double l = (row > k) ? a[k] * rp : 0.0;   // l == 0 leaves rows <= k untouched
+        if (row > k) a[k] = l;
+        static_for<G - 1 - k>([&](auto jc) {
+          constexpr int j = k + 1 + decltype(jc)::value;
+          const double u = bcast<G, k>(a[j]);
+          a[j] = __builtin_fma(-l, u, a[j]);
+        });
+      }
+    });
+  }
+  __device__ __forceinline__ double solve(double x, const int S, const int row, const int lane) const {
+    static_for<G - 1>([&](auto kc) {                     // L z = x (unit lower)
+      constexpr int k = decltype(kc)::value;
+      const double xk = bcast<G, k>(x);
+      if (row > k) x = __builtin_fma(-a[k], xk, x);
+    });
+    static_for<G - 1>([&](auto kc) {                     // U x = z
+      constexpr int k = G - 1 - decltype(kc)::value;
+      const double xk = bcast<G, k>(x * dinv);
+      if (row < k) x = __builtin_fma(-a[k], xk, x);
+    });
+    return x * dinv;
+  }
+};
+
+// DIST: rows >= 2 couple only to row 1 (column 1 and the diagonal), row 1 couples to row 0 and all sites.
+template <int G>
+struct ArrowSolver {
+  double winv;   // 1 / (g - J[row][row])
+  double cw;     // rows >= 2: S_i * winv
+  double sinv;   // 1 / Schur complement of row 1 (uniform)
+  double C;      // J[1][0] (uniform)
+  __device__ __forceinline__ void factor(const RowCoef& c, const double g, const int S, const int row, const int lane) {
+    const double w = (row < S) ? g - c.dg : 1.0;
+    winv = fast_rcp(w);
+    const bool site = (row >= 2 && row < S);
+    cw = site ? c.c1 * winv : 0.0;
+    const double sum = gsum<G>(cw, lane);               // sum_i S_i / w_i  (J[1][i] = 1)
+    const double w1 = bcast<G, 1>(w);
+    sinv = fast_rcp(w1 - sum);
+    C = bcast<G, 1>(c.c2);
+  }
+  __device__ __forceinline__ double solve(double r, const int S, const int row, const int lane) const {
+    const double t = r * winv;
+    const double x0 = bcast<G, 0>(t);
+    const double r1 = bcast<G, 1>(r);
+    const bool site = (row >= 2 && row < S);
+    const double sum = gsum<G>(site ? t : 0.0, lane);
+    const double x1 = (__builtin_fma(C, x0, r1) + sum) * sinv;
+    const double xs = __builtin_fma(cw, x1, t);
+    return (row == 1) ? x1 : xs;                        // row 0: cw == 0 -> t
+  }
+};
+
+// SUCC: parallel cyclic reduction.  Level d (1, 2, 4, ...): row i eliminates its couplings to i-d and i+d.
+template <int G>
+struct TridiagSolver {
+  static constexpr int LV = (G == 8) ? 3 : (G == 16) ? 4 : (G == 32) ? 5 : 6;
+  double kl[LV], ku[LV];   // multipliers per level
+  double binv;             // 1 / final diagonal
+  __device__ __forceinline__ void factor(const RowCoef& c, const double g, const int S, const int row, const int lane) {
+    // row i:  lo * x[i-1] + b * x[i] + up * x[i+1] = r[i]
+    double lo = (row < S && row >= 1) ? -c.c1 : 0.0;
+    double up = (row + 1 < S) ? -c.c2 : 0.0;
+    double b = (row < S) ? g - c.dg : 1.0;
+    static_for<LV>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int d = 1 << l;
+      const bool hl = (row - d >= 0), hu = (row + d < G);
+      const double b_m = gshfl<G>(b, row - d, lane), b_p = gshfl<G>(b, row + d, lane);
+      const double lo_m = gshfl<G>(lo, row - d, lane), up_m = gshfl<G>(up, row - d, lane);
+      const double lo_p = gshfl<G>(lo, row + d, lane), up_p = gshfl<G>(up, row + d, lane);
+      const double k1 = hl ? lo * fast_rcp(b_m) : 0.0;
+      const double k2 = hu ? up * fast_rcp(b_p) : 0.0;
+      kl[l] = k1; ku[l] = k2;
+      b = b - k1 * (hl ? up_m : 0.0) - k2 * (hu ? lo_p : 0.0);
+      lo = hl ? -k1 * lo_m : 0.0;
+      up = hu ? -k2 * up_p : 0.0;
+    });
+    binv = fast_rcp(b);
+  }
+  __device__ __forceinline__ double solve(double r, const int S, const int row, const int lane) const {
+    static_for<LV>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int d = 1 << l;
+      const double r_m = gshfl<G>(r, row - d, lane), r_p = gshfl<G>(r, row + d, lane);
+      r = __builtin_fma(-kl[l], r_m, r);                // kl / ku are 0 where the neighbour does not exist
+      r = __builtin_fma(-ku[l], r_p, r);
+    });
+    return r * binv;
+  }
+};
+
+template <int MODEL, int G, bool STRUCTURED> struct SolverFor { using type = DenseSolver<MODEL, G>; };
+template <int G> struct SolverFor<M_DIST, G, true> { using type = ArrowSolver<G>; };
+template <int G> struct SolverFor<M_SUCC, G, true> { using type = TridiagSolver<G>; };
+
+}  // namespace pk
