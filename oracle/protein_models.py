@@ -330,3 +330,68 @@ def band_error(y, y_ref, rtol=1e-6, atol=1e-8) -> float:
     """max |y - y_ref| / (atol + rtol |y_ref|)  -- the parity gate of BASELINE.json (pass <= 1)."""
     y = np.asarray(y); y_ref = np.asarray(y_ref)
     return float(np.max(np.abs(y - y_ref) / (atol + rtol * np.abs(y_ref))))
+
+
+# --------------------------------------------------------------- CPU baseline helpers (bench.py cpu_baseline leg)
+def rhs_dist_vec(y, t, A, B, C, D, S, Dr):
+    """distmod.py:7-65 with the per-site loops as numpy vector ops (the reference runs them Numba-compiled; a pure-Python
+    loop would overstate the CPU cost by ~10x).  Same arithmetic up to summation order."""
+    dy = np.empty_like(y)
+    P = y[1]
+    dy[0] = A - B * y[0]
+    dy[1] = C * y[0] - (D + S.sum()) * P + y[2:].sum()
+    dy[2:] = S * P - (1.0 + Dr) * y[2:]
+    return dy
+
+
+def rhs_succ_vec(y, t, A, B, C, D, S, Dr):
+    """succmod.py:9-90 vectorised (n >= 2)."""
+    n = S.shape[0]
+    dy = np.empty_like(y)
+    dy[0] = A - B * y[0]
+    dy[1] = C * y[0] - D * y[1] - S[0] * y[1] + y[2]
+    x = y[2:]
+    up = np.empty(n); up[:-1] = x[1:]; up[-1] = 0.0
+    nxt = np.empty(n); nxt[:-1] = S[1:]; nxt[-1] = 0.0
+    dy[2:] = S * y[1:1 + n] - (1.0 + nxt + Dr) * x + up
+    return dy
+
+
+def solve_ode_fast(model: int, params, init_cond, n_sites: int, t):
+    """The reference call shape (odeint at SciPy defaults -> clip -> flat) with the vectorised RHS: the CPU baseline."""
+    A, B, C, D, S, Dr = unpack_params(model, params, n_sites)
+    y0 = np.asarray(init_cond, float)
+    if model == DIST:
+        sol = odeint(rhs_dist_vec, y0, t, args=(A, B, C, D, S, Dr))
+    elif model == SUCC and n_sites >= 2:
+        sol = odeint(rhs_succ_vec, y0, t, args=(A, B, C, D, S, Dr))
+    else:
+        sol = _odeint(model, params, y0, n_sites, t)
+    sol = np.clip(np.asarray(sol), 0, None)
+    return sol, flatten_observables(model, sol, n_sites)
+
+
+def _baseline_worker(args):
+    model, n_sites, thetas, y0, t = args
+    import time as _t
+    t0 = _t.perf_counter()
+    acc = 0.0
+    for th in thetas:
+        sol, flat = solve_ode_fast(model, th, y0, n_sites, t)
+        acc += float(sol[-1, 0])
+    return len(thetas), _t.perf_counter() - t0, acc
+
+
+def cpu_baseline(model: int, n_sites: int, thetas: np.ndarray, y0, t, workers: int):
+    """Fan the sample out over `workers` processes, one chunk each (the reference's shape: one future per parameter vector
+    in a ProcessPoolExecutor, sensitivity/analysis.py:241-243).  Returns (solves_per_second, wall_seconds)."""
+    import time as _t
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing as mp
+    chunks = [c for c in np.array_split(thetas, workers) if len(c)]
+    t0 = _t.perf_counter()
+    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("fork")) as ex:
+        res = list(ex.map(_baseline_worker, [(model, n_sites, c, y0, t) for c in chunks]))
+    wall = _t.perf_counter() - t0
+    busy = max(r[1] for r in res)            # slowest worker's compute time: excludes pool start-up / import cost
+    return sum(r[0] for r in res) / busy, wall

@@ -1,0 +1,29 @@
+"""The handful of import-time constants of the reference that the hot path reads (config/constants.py), as plain
+module attributes.  The reference fixes them at import from config.toml; here they can also be set at run time
+(``phoskintime_amd.models.set_model``) or through environment variables, because the engine takes the model as an
+explicit argument.
+
+  ODE_MODEL                config/constants.py:27   (config.toml:186 default "randmod")     env PHOSKIN_ODE_MODEL
+  NORMALIZE_MODEL_OUTPUT   config/constants.py:73   (config.toml:208 false)                 env PHOSKIN_NORMALIZE
+  TIME_POINTS / _RNA       config/constants.py:56-69
+  Y_METRIC                 config/constants.py:104  ("total_signal")                        env PHOSKIN_Y_METRIC
+  PERTURBATIONS_VALUE      config/constants.py:45   (config.toml:222 0.5)
+"""
+import os
+import numpy as np
+
+ODE_MODEL = os.environ.get("PHOSKIN_ODE_MODEL", "randmod")
+NORMALIZE_MODEL_OUTPUT = os.environ.get("PHOSKIN_NORMALIZE", "0").lower() in ("1", "true", "yes")
+Y_METRIC = os.environ.get("PHOSKIN_Y_METRIC", "total_signal")
+PERTURBATIONS_VALUE = 0.5
+NUM_TRAJECTORIES = 1000
+PARAMETER_SPACE = 400
+
+TIME_POINTS = np.array([0.0, 0.5, 0.75, 1.0, 2.0, 4.0, 8.0, 16.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
+TIME_POINTS_RNA = np.array([4.0, 8.0, 15.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
+
+# composite score weights, config/constants.py:77-83
+ALPHA_WEIGHT = BETA_WEIGHT = GAMMA_WEIGHT = DELTA_WEIGHT = MU_WEIGHT = 1.0
+
+#: engine defaults for the single-call drop-ins (include/phoskin.h pk_default_opts)
+SOLVER_OPTS: dict = {}

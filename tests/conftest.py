@@ -1,0 +1,28 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_files():
+    files = sorted((ROOT / "tests" / "golden").glob("protein_*.npz"))
+    assert files, "tests/golden is empty: run tools/make_golden.py in the build container"
+    return files
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libphoskin_hip.so, built on demand (hipcc cross-compiles for gfx950 without a GPU)."""
+    import __graft_entry__ as g
+    g.build()
+    from phoskintime_amd import _capi
+    return _capi.load()

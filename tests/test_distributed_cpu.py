@@ -1,0 +1,65 @@
+"""CPU, world_size 2, gloo: the partition + single all-gather that carries the N > 1 path (phoskintime_amd/distributed.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from phoskintime_amd.distributed import shard_bounds, all_gather_replicas, sharded_map
+
+
+def test_shard_bounds_cover_exactly_once():
+    for total in (0, 1, 7, 8, 9, 65536, 25728):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            assert sum(b - a for a, b in spans) == total
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def fn(lo, hi):          # stand-in for the kernel: a per-replica result that encodes the global index
+            idx = torch.arange(lo, hi, dtype=torch.float64)
+            return torch.stack([idx, idx * idx + rank * 0.0], dim=1)
+        full = sharded_map(fn, total)
+        ok = full.shape == (total, 2) and torch.equal(full[:, 0], torch.arange(total, dtype=torch.float64)) \
+            and torch.equal(full[:, 1], full[:, 0] ** 2)
+        lo, hi = shard_bounds(total, rank, world)
+        one = all_gather_replicas(torch.full((hi - lo,), float(rank), dtype=torch.float64), total)
+        ok = ok and one.shape == (total,) and float(one.sum()) == float(sum(r * (shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]) for r in range(world)))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [10, 11, 1])
+def test_sharded_map_gloo_world2(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_single_rank_passthrough():
+    x = torch.arange(5.0)
+    assert all_gather_replicas(x, 5) is x
+    assert torch.equal(sharded_map(lambda lo, hi: torch.arange(lo, hi, dtype=torch.float64), 4), torch.arange(4, dtype=torch.float64))
