@@ -3,7 +3,7 @@
 
 Workload (config.workload): BASELINE config 3 -- 65 536 parameter vectors theta ~ U(0, 20)^64 (the reference's config bounds,
 config.toml:189-195) per GPU, models.distmod with 30 phosphosites (S = 32), y0 = 1, the reference's 14-point time grid; one
-"step" = one pass of the hot path over that batch: solve (adaptive RODAS4, analytic Jacobian) -> clip -> trajectories [B,14,32]
+"step" = one pass of the hot path over that batch: solve (adaptive LRP8 by default, analytic Jacobian) -> clip -> trajectories [B,14,32]
 written to HBM + the fused Morris scalar per replica, then -- for N > 1 -- ONE all-gather (RCCL) of the per-replica scalars.
 Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns its own 65 536 replicas.
 
@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-7)
     ap.add_argument("--atol", type=float, default=1e-9)
     ap.add_argument("--linsolve", default="auto")
-    ap.add_argument("--method", default="rodas4")
+    ap.add_argument("--method", default="lrp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="replicas in the CPU baseline sample (0 = 128 per core)")
     args = ap.parse_args()
@@ -119,8 +119,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: 65536 replicas/GPU, models.distmod n_sites=30 (S=32, P=64), theta~U(0,20), "
-                                   "y0=1, 14-point grid 0..960, adaptive RODAS4 rtol=%g atol=%g, linsolve=%s; outputs sol[B,14,32] + "
-                                   "Morris total_signal[B]%s" % (args.rtol, args.atol, args.linsolve,
+                                   "y0=1, 14-point grid 0..960, adaptive %s rtol=%g atol=%g, linsolve=%s; outputs sol[B,14,32] + "
+                                   "Morris total_signal[B]%s" % (args.method, args.rtol, args.atol, args.linsolve,
                                                                "; 1 RCCL all-gather of Y per step" if world > 1 else ""),
                        "replicas_per_gpu": B, "n_states": S, "n_params": P, "n_timepoints": T, "method": args.method,
                        "parallelism": "replica-sharded x%d" % world},
@@ -131,7 +131,7 @@ def main():
         }
         # parity on the first 64 replicas of this very batch against the committed SciPy reference trajectories
         gfile = ROOT / "tests" / "golden" / "protein_distmod_n30_c3bounds.npz"
-        if gfile.exists() and args.method == "rodas4" and B >= 64:
+        if gfile.exists() and args.method in ("rodas4", "lrp8") and B >= 64:
             g = np.load(gfile)
             if np.array_equal(g["theta"], theta_h[:64]):
                 sol64 = out.sol[:64].cpu().numpy()

@@ -30,16 +30,19 @@ extern "C" {
 
 enum { PK_MODEL_DIST = 0, PK_MODEL_SUCC = 1, PK_MODEL_RAND = 2 };
 
-/* Integrators.  RODAS4 is the default and the one the parity gate is stated for. */
+/* Integrators (all adaptive ones: max-norm local error control, steps land exactly on every t[k]).
+ * LRP8 is the default: the three per-protein models are affine in y (constant Jacobian), which it exploits. */
 enum {
-  PK_METHOD_RODAS4 = 0, /* adaptive 6-stage L-stable Rosenbrock 4(3) (Hairer-Wanner RODAS), analytic Jacobian, 1 LU / step */
-  PK_METHOD_BDF2   = 1, /* variable-step BDF2 (BDF1 start), analytic Jacobian, LU per step-size change (BASELINE config 3) */
-  PK_METHOD_RK4    = 2  /* classical explicit RK4, fixed step h <= rk4_h (BASELINE config 2); stability-bound when stiff */
+  PK_METHOD_RODAS4 = 0, /* 6-stage L-stable Rosenbrock 4(3) (Hairer-Wanner RODAS), analytic Jacobian, 1 factorisation / step */
+  PK_METHOD_BDF2   = 1, /* variable-step BDF2 (BDF1 start), analytic Jacobian, 1 factorisation / step (BASELINE config 3) */
+  PK_METHOD_RK4    = 2, /* classical explicit RK4, fixed step h <= rk4_h (BASELINE config 2); stability-bound when stiff */
+  PK_METHOD_LRP8   = 3  /* L-stable restricted-Pade one-step method for affine systems: 8 resolvent solves, 1 rhs and
+                           1 factorisation per step, order 7 with an embedded order-6 estimate */
 };
 
 /* Linear solver for the implicit stage equations (g I - J) x = r. */
 enum {
-  PK_LINSOLVE_AUTO       = 0, /* structured where the model has one, else dense */
+  PK_LINSOLVE_AUTO       = 0, /* fastest available: distmod + RODAS4 -> throughput kernel (4-16 lanes per replica); else structured / dense */
   PK_LINSOLVE_DENSE      = 1, /* dense in-register LU, one matrix row per lane, cross-lane broadcasts (any model) */
   PK_LINSOLVE_STRUCTURED = 2  /* arrow (distmod) / tridiagonal (succmod) elimination; randmod falls back to dense */
 };
@@ -65,7 +68,8 @@ typedef struct pk_solver_opts {
   int32_t max_steps;    /* per replica, accepted + rejected; default 100000                   */
   int32_t clip_nonneg;  /* np.clip(sol, 0, None) as in distmod.py:112-113 (default 1)         */
   int32_t normalize;    /* NORMALIZE_MODEL_OUTPUT: sol *= 1 / y0 (distmod.py:116-122)         */
-  int32_t reserved;
+  int32_t stage_form;   /* RODAS4: 0 = resolvent form (1 rhs + 6 solves / step; exact for the affine per-protein models),
+                           1 = classical 6-stage Rosenbrock form (same method; kept for nonlinear right-hand sides) */
 } pk_solver_opts;
 
 typedef struct pk_ctx pk_ctx;

@@ -87,7 +87,7 @@ def solve_ode_batch(model, theta: ArrayLike, init_cond: ArrayLike, num_psites: i
                     method: Union[str, int, None] = None, linsolve: Union[str, int, None] = None,
                     rtol: Optional[float] = None, atol: Optional[float] = None, h0: Optional[float] = None,
                     rk4_h: Optional[float] = None, max_steps: Optional[int] = None,
-                    clip_nonneg: bool = True, normalize: bool = False,
+                    clip_nonneg: bool = True, normalize: bool = False, stage_form: int = 0,
                     device: Optional[int] = None, out: Optional[BatchResult] = None) -> BatchResult:
     """Integrate B replicas of one per-protein model.  ``theta`` is [B, P]; ``init_cond`` [S] (shared) or [B, S].
 
@@ -117,7 +117,7 @@ def solve_ode_batch(model, theta: ArrayLike, init_cond: ArrayLike, num_psites: i
         raise ValueError("t must hold at least one time point")
     F = flat_len(mid, n, T)
     opts = default_opts(method=method, linsolve=linsolve, rtol=rtol, atol=atol, h0=h0, rk4_h=rk4_h, max_steps=max_steps,
-                        clip_nonneg=int(bool(clip_nonneg)), normalize=int(bool(normalize)))
+                        clip_nonneg=int(bool(clip_nonneg)), normalize=int(bool(normalize)), stage_form=int(stage_form))
     if out is None:
         out = BatchResult(
             sol=torch.empty((B, T, S), dtype=torch.float64, device=dev) if want_sol else None,

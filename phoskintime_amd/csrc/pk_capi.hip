@@ -55,7 +55,7 @@ int pk_version(void) { return PK_VERSION; }
 void pk_default_opts(pk_solver_opts* o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
-  o->method = PK_METHOD_RODAS4;
+  o->method = PK_METHOD_LRP8;
   o->linsolve = PK_LINSOLVE_AUTO;
   o->rtol = 1e-7;
   o->atol = 1e-9;
@@ -134,7 +134,7 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   if (metric && (metric_id < 0 || metric_id > 4)) return fail(c, PK_ERR_ARG, "unknown metric_id");
   pk_solver_opts o;
   if (opts_in) o = *opts_in; else pk_default_opts(&o);
-  if (o.method < 0 || o.method > 2) return fail(c, PK_ERR_ARG, "unknown method");
+  if (o.method < 0 || o.method > 3) return fail(c, PK_ERR_ARG, "unknown method");
   if (o.method != PK_METHOD_RK4 && !(o.rtol > 0.0 && o.atol >= 0.0)) return fail(c, PK_ERR_ARG, "rtol must be > 0 and atol >= 0");
   if (o.method == PK_METHOD_RK4 && !(o.rk4_h > 0.0)) return fail(c, PK_ERR_ARG, "rk4_h must be > 0");
   if (o.max_steps <= 0) o.max_steps = 100000;
@@ -143,7 +143,7 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   a.theta = theta; a.y0 = y0; a.t = t; a.sol = sol; a.flat = flat; a.metric = metric; a.status = status; a.n_steps = n_steps;
   a.B = B; a.n_sites = n_sites; a.S = pk::n_states(model, n_sites); a.P = pk::n_params(model, n_sites); a.T = T;
   a.F = pk_protein_flat_len(model, n_sites, T); a.n_obs = n_sites; a.y0_batched = y0_is_batched ? 1 : 0; a.metric_id = metric_id;
-  a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.rk4_h = o.rk4_h; a.max_steps = o.max_steps; a.clip = o.clip_nonneg; a.normalize = o.normalize;
+  a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.rk4_h = o.rk4_h; a.max_steps = o.max_steps; a.clip = o.clip_nonneg; a.normalize = o.normalize; a.stage_form = o.stage_form;
 
   const int G = group_width(a.S);
   const long long rpb = 256 / G;
@@ -152,7 +152,10 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   const bool structured = (o.linsolve != PK_LINSOLVE_DENSE) && (model != PK_MODEL_RAND);
   PK_HIP(c, hipSetDevice(c->device));
   dim3 grid((unsigned)nblk);
-  kSolve[model][gidx(G)](a, o.method, structured, grid, c->stream);
+  if (model == PK_MODEL_DIST && (o.method == PK_METHOD_RODAS4 || o.method == PK_METHOD_LRP8) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
+    pk::launch_dist_fast(a, o.method, c->stream);                      // throughput layout: 4-16 lanes per replica, shadowed R / P rows
+  else
+    kSolve[model][gidx(G)](a, o.method, structured, grid, c->stream);
   PK_HIP(c, hipGetLastError());
   return PK_OK;
 }

@@ -18,4 +18,7 @@ PK_DECL(1, 8) PK_DECL(1, 16) PK_DECL(1, 32) PK_DECL(1, 64)
 PK_DECL(2, 8) PK_DECL(2, 16) PK_DECL(2, 32) PK_DECL(2, 64)
 #undef PK_DECL
 
+// distributive-model throughput kernel (pk_dist_fast.hpp): RODAS4, arrow elimination, 4-16 lanes per replica
+void launch_dist_fast(const SolveArgs&, int method, hipStream_t);
+
 }  // namespace pk

@@ -19,7 +19,7 @@ struct SolveArgs {
   const double* theta; const double* y0; const double* t;
   double* sol; double* flat; double* metric; int32_t* status; int32_t* n_steps;
   long long B; int n_sites; int S; int P; int T; int F; int n_obs; int y0_batched; int metric_id;
-  double rtol, atol, h0, rk4_h; int max_steps; int clip; int normalize;
+  double rtol, atol, h0, rk4_h; int max_steps; int clip; int normalize; int stage_form;
 };
 
 // ------------------------------------------------------------------ RODAS4 (Hairer & Wanner, rodas.f METH=1)
@@ -33,7 +33,42 @@ constexpr double C21 = -0.5668800000000000e+01, C31 = -0.2430093356833875e+01, C
 constexpr double C41 = -0.1073529058151375e+00, C42 = -0.9594562251023355e+01, C43 = -0.2047028614809616e+02;
 constexpr double C51 = 0.7496443313967647e+01, C52 = -0.1024680431464352e+02, C53 = -0.3399990352819905e+02, C54 = 0.1170890893206160e+02;
 constexpr double C61 = 0.8083246795921522e+01, C62 = -0.7981132988064893e+01, C63 = -0.3152159432874371e+02, C64 = 0.1631930543123136e+02, C65 = -0.6058818238834054e+01;
+// Resolvent form for affine right-hand sides (tools/rodas4_resolvent.py, 60-digit arithmetic): with M = I - GAM h J,
+// z_1 = M^{-1} h f(y_n), z_{k+1} = M^{-1} z_k:  y_{n+1} = y_n + sum RB_k z_k,  err = sum RE_k z_k  (RE_1 = 0).
+constexpr double RB1 = 0.25, RB2 = -0.30261563040255475781, RB3 = 2.0437958549435498747, RB4 = -1.1490271157486588988,
+                 RB5 = 0.12712918827688397052, RB6 = 0.030717702930779034113;
+constexpr double RE2 = -0.27896255898136486925, RE3 = 0.80616997401331598084, RE4 = -0.74473456815175834943,
+                 RE5 = 0.18680945018902833694, RE6 = 0.030717702930779034113;
 }  // namespace r4
+
+// Resolvent-form one-step methods for affine systems:  M = I - GAM h J, z_1 = M^{-1} h f(y_n), z_{k+1} = M^{-1} z_k,
+//   y_{n+1} = y_n + sum_k B[k] z_k ,  err = sum_k E[k] z_k ,  step-size exponent 1 / Q  (Q = order of the estimator + 1).
+template <int METHOD> struct ResolventTab;
+template <> struct ResolventTab<PK_METHOD_RODAS4> {          // RODAS4 rewritten for affine f (tools/rodas4_resolvent.py)
+  static constexpr int NS = 6;
+  static constexpr double GAM = 0.25;
+  static constexpr double Q = 4.0;
+  static constexpr double B[6] = {r4::RB1, r4::RB2, r4::RB3, r4::RB4, r4::RB5, r4::RB6};
+  static constexpr double E[6] = {0.0, r4::RE2, r4::RE3, r4::RE4, r4::RE5, r4::RE6};
+};
+// LRP8: L-stable restricted-Pade approximation of exp with 8 resolvent solves, order 7, embedded order 6 on z_1..z_7
+// (both A-stable with R(inf) = 0; gamma = 0.22 lies in the s = 8 window [0.1567, 0.2344] of Hairer & Wanner II, Table IV.6.4;
+// weights from the order conditions in 60-digit arithmetic: tools/restricted_pade.py 8 0.22).
+template <> struct ResolventTab<PK_METHOD_LRP8> {
+  static constexpr int NS = 8;
+  static constexpr double GAM = 0.22;
+  static constexpr double Q = 7.0;
+  static constexpr double B[8] = {0.22, 0.896963014494355498137, -4.05804045796110421602, 10.5343409578260650281,
+                                  -11.197471732915163878, 6.15403680296552740685, -1.75732530837770792816, 0.207496723968028089083};
+  static constexpr double E[8] = {0.0, 0.207496723968028089083, -1.2449803438081685345, 3.11245085952042133624,
+                                  -4.14993447936056178166, 3.11245085952042133624, -1.2449803438081685345, 0.207496723968028089083};
+};
+
+// err^(1/Q) for the step-size controller: single precision is ample (the factor is clamped to [1/6, 5] anyway)
+__device__ __forceinline__ double root_q(double err, double Q) {
+  const float e = (float)fmin(fmax(err, 1e-30), 1e30);
+  return (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(e) * (float)(1.0 / Q));
+}
 
 // Per-replica output / reduction state (one value per lane = per state row).
 template <int G>
@@ -99,7 +134,9 @@ struct Emitter {
   }
 };
 
-template <int MODEL, int G, int METHOD, bool STRUCTURED>
+// RESOLVENT: RODAS4 only -- use the resolvent form (valid because every per-protein model is affine in y); false =
+// the classical 6-stage form that a nonlinear right-hand side needs.
+template <int MODEL, int G, int METHOD, bool STRUCTURED, bool RESOLVENT = true>
 __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
   constexpr int RPB = 256 / G;                           // replicas per block
   const int lane = lane_id();
@@ -162,8 +199,11 @@ __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
       if (!(h > 0.0) || h != h) h = 1e-6;
     }
 
-    if constexpr (METHOD == PK_METHOD_RODAS4) {
+    if constexpr (METHOD == PK_METHOD_RODAS4 || METHOD == PK_METHOD_LRP8) {
       using namespace r4;
+      constexpr bool RES = RESOLVENT || METHOD == PK_METHOD_LRP8;
+      using Tab = ResolventTab<METHOD>;
+      constexpr double GAMMA = Tab::GAM;
       bool after_reject = false;
       while (true) {
         if (nacc + nrej >= A.max_steps) { status |= PK_ST_MAXSTEPS; out.fill_nan(k); break; }
@@ -171,16 +211,31 @@ __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
         const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
         if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; out.fill_nan(k); break; }
         const double hinv = 1.0 / hs;
-        ls.factor(c, hinv * (1.0 / GAM), S, row, lane);
+        const double gW = hinv * (1.0 / GAMMA);                          // W = gW I - J = M / (GAMMA h)
+        ls.factor(c, gW, S, row, lane);
+        double yn, u6;
+        if constexpr (RES) {
+          // z_1 = M^{-1} h f(y) = W^{-1} f(y) / GAMMA ; z_{k+1} = M^{-1} z_k = gW W^{-1} z_k
+          double z = ls.solve(f_of(y), S, row, lane) * (1.0 / GAMMA);
+          yn = __builtin_fma(Tab::B[0], z, y);
+          u6 = 0.0;
+          static_for<Tab::NS - 1>([&](auto kc) {
+            constexpr int kk = 1 + decltype(kc)::value;
+            z = ls.solve(z, S, row, lane) * gW;
+            yn = __builtin_fma(Tab::B[kk], z, yn);
+            u6 = __builtin_fma(Tab::E[kk], z, u6);
+          });
+        } else {
         const double u1 = ls.solve(f_of(y), S, row, lane);
         const double u2 = ls.solve(__builtin_fma(C21 * hinv, u1, f_of(__builtin_fma(A21, u1, y))), S, row, lane);
         const double u3 = ls.solve(f_of(y + (A31 * u1 + A32 * u2)) + hinv * (C31 * u1 + C32 * u2), S, row, lane);
         const double u4 = ls.solve(f_of(y + (A41 * u1 + A42 * u2 + A43 * u3)) + hinv * (C41 * u1 + C42 * u2 + C43 * u3), S, row, lane);
-        double yn = y + (A51 * u1 + A52 * u2 + A53 * u3 + A54 * u4);
+        yn = y + (A51 * u1 + A52 * u2 + A53 * u3 + A54 * u4);
         const double u5 = ls.solve(f_of(yn) + hinv * (C51 * u1 + C52 * u2 + C53 * u3 + C54 * u4), S, row, lane);
         yn += u5;
-        const double u6 = ls.solve(f_of(yn) + hinv * (C61 * u1 + C62 * u2 + C63 * u3 + C64 * u4 + C65 * u5), S, row, lane);
+        u6 = ls.solve(f_of(yn) + hinv * (C61 * u1 + C62 * u2 + C63 * u3 + C64 * u4 + C65 * u5), S, row, lane);
         yn += u6;
+        }
         const double sc = __builtin_fma(rtol, fmax(fabs(y), fabs(yn)), atol);
         const double err = gmax<G>(fabs(u6) / sc, lane);                // NaN-propagating
         if (err != err || err > 1e300) {
@@ -189,7 +244,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
           if (gmax<G>((y - y != 0.0) ? 1.0 : 0.0, lane) != 0.0) { status |= PK_ST_NONFINITE; out.fill_nan(k); break; }
           continue;
         }
-        double fac = sqrt(sqrt(err)) * (1.0 / 0.9);
+        double fac = root_q(err, Tab::Q) * (1.0 / 0.9);
         fac = fmax(1.0 / 6.0, fmin(5.0, fac));
         double hnew = hs / fac;
         if (err <= 1.0) {

@@ -6,6 +6,7 @@
 // inside the group and never touches LDS memory:
 //   * G == 64 : v_readlane_b32 (value lands in SGPRs and feeds v_fma_f64 as a scalar operand)
 //   * G <  64 : ds_swizzle_b32 in bit-mask mode (LDS crossbar, no LDS storage, no address VGPR)
+//   * reductions: DPP (quad_perm / row_half_mirror / row_mirror) up to 16 lanes, then swizzle / bpermute
 //   * runtime source lane: ds_bpermute_b32
 #pragma once
 #include <hip/hip_runtime.h>
@@ -52,85 +53,58 @@ __device__ __forceinline__ double gshfl(double v, int src, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-template <int MASK>
-__device__ __forceinline__ double xor_lane(double v, int lane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  if constexpr (MASK < 32) {
-    constexpr int pat = 0x1f | (MASK << 10);
-    lo = __builtin_amdgcn_ds_swizzle(lo, pat);
-    hi = __builtin_amdgcn_ds_swizzle(hi, pat);
-  } else {
-    const int addr = (lane ^ 32) << 2;
-    lo = __builtin_amdgcn_ds_bpermute(addr, lo);
-    hi = __builtin_amdgcn_ds_bpermute(addr, hi);
-  }
+// ---- butterfly partners.  Levels 1..8 stay in the VALU (DPP: quad_perm / row_half_mirror / row_mirror, ~1 issue slot
+// per dword, no LDS-crossbar trip); level 16 uses ds_swizzle, level 32 ds_bpermute.  Mirrors instead of XORs at levels
+// 4 and 8 pair the same sub-groups, and every lane of a group still ends with the bit-identical result (fp add and
+// max are commutative, and the tree shape is the same for all lanes).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
-// all-reduce over the group (xor butterfly: every lane ends with the bit-identical result)
+template <int LEVEL>
+__device__ __forceinline__ double partner(double v, int lane) {
+  if constexpr (LEVEL == 1) return dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+  else if constexpr (LEVEL == 2) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  else if constexpr (LEVEL == 4) return dpp_mov<0x141>(v);  // row_half_mirror: i <-> 7 - i
+  else if constexpr (LEVEL == 8) return dpp_mov<0x140>(v);  // row_mirror: i <-> 15 - i
+  else if constexpr (LEVEL == 16) {
+    constexpr int pat = 0x1f | (16 << 10);                  // ds_swizzle bit-mask mode, xor 16
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+    return __hiloint2double(hi, lo);
+  } else {
+    const int addr = (lane ^ 32) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+}
+
+// all-reduce over the group: every lane ends with the bit-identical result
 template <int G>
 __device__ __forceinline__ double gsum(double v, int lane) {
-  if constexpr (G >= 2)  v += xor_lane<1>(v, lane);
-  if constexpr (G >= 4)  v += xor_lane<2>(v, lane);
-  if constexpr (G >= 8)  v += xor_lane<4>(v, lane);
-  if constexpr (G >= 16) v += xor_lane<8>(v, lane);
-  if constexpr (G >= 32) v += xor_lane<16>(v, lane);
-  if constexpr (G >= 64) v += xor_lane<32>(v, lane);
+  if constexpr (G >= 2)  v += partner<1>(v, lane);
+  if constexpr (G >= 4)  v += partner<2>(v, lane);
+  if constexpr (G >= 8)  v += partner<4>(v, lane);
+  if constexpr (G >= 16) v += partner<8>(v, lane);
+  if constexpr (G >= 32) v += partner<16>(v, lane);
+  if constexpr (G >= 64) v += partner<32>(v, lane);
   return v;
 }
 template <int G>
 __device__ __forceinline__ double gmax(double v, int lane) {
   // NaN-propagating max: a NaN anywhere in the group must surface (fmax would swallow it)
   auto mx = [](double a, double b) { return (a > b || a != a) ? a : b; };
-  if constexpr (G >= 2)  v = mx(v, xor_lane<1>(v, lane));
-  if constexpr (G >= 4)  v = mx(v, xor_lane<2>(v, lane));
-  if constexpr (G >= 8)  v = mx(v, xor_lane<4>(v, lane));
-  if constexpr (G >= 16) v = mx(v, xor_lane<8>(v, lane));
-  if constexpr (G >= 32) v = mx(v, xor_lane<16>(v, lane));
-  if constexpr (G >= 64) v = mx(v, xor_lane<32>(v, lane));
+  if constexpr (G >= 2)  v = mx(v, partner<1>(v, lane));
+  if constexpr (G >= 4)  v = mx(v, partner<2>(v, lane));
+  if constexpr (G >= 8)  v = mx(v, partner<4>(v, lane));
+  if constexpr (G >= 16) v = mx(v, partner<8>(v, lane));
+  if constexpr (G >= 32) v = mx(v, partner<16>(v, lane));
+  if constexpr (G >= 64) v = mx(v, partner<32>(v, lane));
   return v;
-}
-
-// ------------------------------------------------------------------ dense in-register LU
-// Row-per-lane storage: lane `row` holds a[0..G) = row `row` of W.  No pivoting: for every model on this
-// path W = g I - J with J a compartmental (Metzler, column-sum <= 0) matrix, so W is a column-diagonally-
-// dominant M-matrix and Gaussian elimination without pivoting is backward stable.
-// On exit a[] holds L (unit lower, multipliers) below the diagonal and U on/above it; dinv = 1 / U[row][row].
-template <int G>
-__device__ __forceinline__ void lu_factor(double (&a)[G], const int row, double& dinv) {
-  static_for<G>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    const double piv = bcast<G, k>(a[k]);
-    const double rp = 1.0 / piv;
-    if (row == k) dinv = rp;
-    if constexpr (k + 1 < G) {
-      const double l = (row > k) ? a[k] * rp : 0.0;   // l == 0 leaves rows <= k untouched
-      if (row > k) a[k] = l;
-      static_for<G - 1 - k>([&](auto jc) {
-        constexpr int j = k + 1 + decltype(jc)::value;
-        const double u = bcast<G, k>(a[j]);
-        a[j] = __builtin_fma(-l, u, a[j]);
-      });
-    }
-  });
-}
-
-// x <- W^{-1} x using the factors above (x distributed one element per lane)
-template <int G>
-__device__ __forceinline__ double lu_solve(const double (&a)[G], const int row, const double dinv, double x) {
-  // forward: L z = x (unit lower)
-  static_for<G - 1>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    const double xk = bcast<G, k>(x);
-    if (row > k) x = __builtin_fma(-a[k], xk, x);
-  });
-  // backward: U x = z ; lane k's value is final once every k' > k has been eliminated
-  static_for<G - 1>([&](auto kc) {
-    constexpr int k = G - 1 - decltype(kc)::value;
-    const double xk = bcast<G, k>(x * dinv);
-    if (row < k) x = __builtin_fma(-a[k], xk, x);
-  });
-  return x * dinv;
 }
 
 }  // namespace pk

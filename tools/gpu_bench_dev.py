@@ -28,9 +28,16 @@ def run(model, n, B, method, lin, lo=0.0, hi=20.0, rtol=1e-7, atol=1e-9, iters=3
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if which in ('all', 'c3', 'lrp'):
+        for meth in ('lrp8', 'rodas4'):
+            for lin in ('auto', 'structured', 'dense'):
+                run(0, 30, 65536 if lin != 'dense' else 16384, meth, lin)
+            run(1, 14, 65536, meth, 'structured')
+            run(1, 14, 16384, meth, 'dense')
+            run(2, 4, 16384, meth, 'dense')
+            run(2, 5, 4096, meth, 'dense')
+            run(0, 4, 65536, meth, 'auto')
     if which in ('all', 'c3'):
-        for lin in ('structured', 'dense'):
-            run(0, 30, 65536, 'rodas4', lin)
         run(0, 30, 65536, 'rodas4', 'structured', 0.05, 2.0)
         run(0, 30, 65536, 'bdf2', 'structured')
         run(0, 30, 8192, 'bdf2', 'dense')
