@@ -129,6 +129,17 @@ def main():
                          "note": "path is FP64-VALU/LDS-crossbar bound, not HBM bound (DESIGN.md); HBM fraction reported as the contract asks"},
             "solver": {"mean_accepted_steps": nst[0], "mean_rejected_steps": nst[1], "flagged_replicas": status_bad},
         }
+        # HBM traffic of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh)
+        pmc = ROOT / "profiles" / "r01_b_dist_fast_lrp8_pmc.json"
+        if pmc.exists() and args.method == "lrp8" and args.linsolve == "auto" and B == 65536:
+            pj = json.loads(pmc.read_text())
+            res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+            res["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)" % pmc.name
+            res["roofline"]["algorithmic_bytes_per_launch"] = B * bytes_per_replica
+            # the binding resource: VALU issue.  f64 VALU ops take 4 cycles per wave64 on a SIMD (16 lanes / clk)
+            res["valu_issue"] = {"valu_insts_per_launch": pj["SQ_INSTS_VALU"], "lds_insts_per_launch": pj["SQ_INSTS_LDS"],
+                                 "busy_frac_at_4clk_2p1GHz": pj["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.1e9 * kernel_ms * 1e-3),
+                                 "note": "1024 SIMDs; clock under FP64 load ~2.1 GHz; counters from the same PMC run"}
         # parity on the first 64 replicas of this very batch against the committed SciPy reference trajectories
         gfile = ROOT / "tests" / "golden" / "protein_distmod_n30_c3bounds.npz"
         if gfile.exists() and args.method in ("rodas4", "lrp8") and B >= 64:

@@ -56,6 +56,38 @@ struct DenseSolver {
   }
 };
 
+// Dense, explicit inverse: in-register Gauss-Jordan (no pivoting, same M-matrix argument), then every solve is a
+// mat-vec whose G broadcasts are independent of each other -- no 2G-long dependent chain as in the triangular solves
+// of DenseSolver, which is what bounds that variant (latency of the cross-lane broadcast, measured).  The price is
+// ~2x the factorisation flops; with 6-8 solves per factorisation (resolvent-form steps) the inverse wins clearly.
+template <int MODEL, int G>
+struct DenseInvSolver {
+  double a[G];           // row `row` of W, then of W^{-1}
+  __device__ __forceinline__ void factor(const RowCoef& c, const double g, const int S, const int row, const int lane) {
+    fill_w_row<MODEL, G>(a, c, g, S, row);
+    static_for<G>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const double rp = fast_rcp(bcast<G, k>(a[k]));
+      // row k: a_kj <- a_kj * rp ; other rows: a_ij <- a_ij - (a_ik rp) a_kj ; both as a_ij - m * a_kj(old)
+      const double m = (row == k) ? 1.0 - rp : a[k] * rp;
+      static_for<G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j != k) a[j] = __builtin_fma(-m, bcast<G, k>(a[j]), a[j]);
+      });
+      a[k] = (row == k) ? rp : -m;
+    });
+  }
+  __device__ __forceinline__ double solve(const double r, const int S, const int row, const int lane) const {
+    double x0 = 0.0, x1 = 0.0;           // two accumulators: halves the fma dependency chain
+    static_for<G / 2>([&](auto jc) {
+      constexpr int j = 2 * decltype(jc)::value;
+      x0 = __builtin_fma(a[j], bcast<G, j>(r), x0);
+      x1 = __builtin_fma(a[j + 1], bcast<G, j + 1>(r), x1);
+    });
+    return x0 + x1;
+  }
+};
+
 // DIST: rows >= 2 couple only to row 1 (column 1 and the diagonal), row 1 couples to row 0 and all sites.
 template <int G>
 struct ArrowSolver {
@@ -124,7 +156,7 @@ struct TridiagSolver {
   }
 };
 
-template <int MODEL, int G, bool STRUCTURED> struct SolverFor { using type = DenseSolver<MODEL, G>; };
+template <int MODEL, int G, bool STRUCTURED> struct SolverFor { using type = DenseInvSolver<MODEL, G>; };
 template <int G> struct SolverFor<M_DIST, G, true> { using type = ArrowSolver<G>; };
 template <int G> struct SolverFor<M_SUCC, G, true> { using type = TridiagSolver<G>; };
 

@@ -5,7 +5,8 @@
 // a wavefront, so S = 32 runs two replicas per wave and S = 6 runs eight.  All cross-lane traffic stays
 // inside the group and never touches LDS memory:
 //   * G == 64 : v_readlane_b32 (value lands in SGPRs and feeds v_fma_f64 as a scalar operand)
-//   * G <  64 : ds_swizzle_b32 in bit-mask mode (LDS crossbar, no LDS storage, no address VGPR)
+//   * G == 16 : DPP row_newbcast (VALU only)
+//   * G == 8, 32: ds_swizzle_b32 in bit-mask mode (LDS crossbar, no LDS storage, no address VGPR)
 //   * reductions: DPP (quad_perm / row_half_mirror / row_mirror) up to 16 lanes, then swizzle / bpermute
 //   * runtime source lane: ds_bpermute_b32
 #pragma once
@@ -35,6 +36,10 @@ __device__ __forceinline__ double bcast(double v) {
   if constexpr (G == 64) {
     lo = __builtin_amdgcn_readlane(lo, K);
     hi = __builtin_amdgcn_readlane(hi, K);
+  } else if constexpr (G == 16) {
+    // DPP row_newbcast:K -- lane K of each 16-lane row to the whole row; stays in the VALU
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
   } else {
     // bit-mask mode: src_lane = ((lane & and_mask) | or_mask) ^ xor_mask within each 32-lane half
     constexpr int pat = ((32 - G) & 0x1f) | (K << 5);
