@@ -154,6 +154,8 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   dim3 grid((unsigned)nblk);
   if (model == PK_MODEL_DIST && (o.method == PK_METHOD_RODAS4 || o.method == PK_METHOD_LRP8) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
     pk::launch_dist_fast(a, o.method, c->stream);                      // throughput layout: 4-16 lanes per replica, shadowed R / P rows
+  else if (model == PK_MODEL_RAND && (o.method == PK_METHOD_RODAS4 || o.method == PK_METHOD_LRP8) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
+    pk::launch_rand_fast(a, o.method, c->stream);                  // 2^n lanes per replica, shadowed mRNA row
   else
     kSolve[model][gidx(G)](a, o.method, structured, grid, c->stream);
   PK_HIP(c, hipGetLastError());

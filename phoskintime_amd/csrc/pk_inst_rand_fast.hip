@@ -1,0 +1,26 @@
+// Instantiations + launcher of the random-model throughput kernel (pk_rand_fast.hpp).
+#include "pk_rand_fast.hpp"
+#include "pk_launch.hpp"
+
+namespace pk {
+
+template <int NB>
+static void launch_nb(const SolveArgs& a, int method, hipStream_t st) {
+  constexpr int G = (1 << NB) < 4 ? 4 : (1 << NB);
+  const long long rpb = 256 / G;
+  const long long nblk = (a.B + rpb - 1) / rpb;
+  if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else                          hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+}
+
+void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {
+  switch (a.n_sites) {
+    case 1: launch_nb<1>(a, method, st); break;
+    case 2: launch_nb<2>(a, method, st); break;
+    case 3: launch_nb<3>(a, method, st); break;
+    case 4: launch_nb<4>(a, method, st); break;
+    default: launch_nb<5>(a, method, st); break;
+  }
+}
+
+}  // namespace pk

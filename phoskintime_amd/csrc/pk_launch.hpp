@@ -20,5 +20,7 @@ PK_DECL(2, 8) PK_DECL(2, 16) PK_DECL(2, 32) PK_DECL(2, 64)
 
 // distributive-model throughput kernel (pk_dist_fast.hpp): RODAS4, arrow elimination, 4-16 lanes per replica
 void launch_dist_fast(const SolveArgs&, int method, hipStream_t);
+// random-model throughput kernel (pk_rand_fast.hpp): RODAS4 / LRP8, in-register Gauss-Jordan on the 2^n coupled rows
+void launch_rand_fast(const SolveArgs&, int method, hipStream_t);
 
 }  // namespace pk

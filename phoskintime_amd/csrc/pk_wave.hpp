@@ -5,8 +5,8 @@
 // a wavefront, so S = 32 runs two replicas per wave and S = 6 runs eight.  All cross-lane traffic stays
 // inside the group and never touches LDS memory:
 //   * G == 64 : v_readlane_b32 (value lands in SGPRs and feeds v_fma_f64 as a scalar operand)
-//   * G == 16 : DPP row_newbcast (VALU only)
-//   * G == 8, 32: ds_swizzle_b32 in bit-mask mode (LDS crossbar, no LDS storage, no address VGPR)
+//   * G == 4, 8, 16 : DPP quad_perm / row_newbcast (VALU only)
+//   * G == 32 : ds_swizzle_b32 in bit-mask mode (LDS crossbar, no LDS storage, no address VGPR)
 //   * reductions: DPP (quad_perm / row_half_mirror / row_mirror) up to 16 lanes, then swizzle / bpermute
 //   * runtime source lane: ds_bpermute_b32
 #pragma once
@@ -40,6 +40,15 @@ __device__ __forceinline__ double bcast(double v) {
     // DPP row_newbcast:K -- lane K of each 16-lane row to the whole row; stays in the VALU
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
+  } else if constexpr (G == 8) {
+    // two bank-masked row_newbcasts: lanes 0-7 of a row take lane K, lanes 8-15 take lane 8 + K
+    const int l0 = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0x3, false);
+    const int h0 = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0x3, false);
+    lo = __builtin_amdgcn_update_dpp(l0, lo, 0x150 + 8 + K, 0xf, 0xc, false);
+    hi = __builtin_amdgcn_update_dpp(h0, hi, 0x150 + 8 + K, 0xf, 0xc, false);
+  } else if constexpr (G == 4) {
+    lo = __builtin_amdgcn_update_dpp(0, lo, K * 0x55, 0xf, 0xf, false);      // quad_perm [K,K,K,K]
+    hi = __builtin_amdgcn_update_dpp(0, hi, K * 0x55, 0xf, 0xf, false);
   } else {
     // bit-mask mode: src_lane = ((lane & and_mask) | or_mask) ^ xor_mask within each 32-lane half
     constexpr int pat = ((32 - G) & 0x1f) | (K << 5);
@@ -84,6 +93,21 @@ __device__ __forceinline__ double partner(double v, int lane) {
     const int addr = (lane ^ 32) << 2;
     const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+}
+
+// value of lane (lane ^ MASK), MASK < 32: exact XOR partner (hypercube neighbours of the randmod bit-mask states)
+template <int MASK>
+__device__ __forceinline__ double xor_partner(double v) {
+  static_assert(MASK > 0 && MASK < 32, "xor mask");
+  if constexpr (MASK == 1) return dpp_mov<0xB1>(v);
+  else if constexpr (MASK == 2) return dpp_mov<0x4E>(v);
+  else if constexpr (MASK == 3) return dpp_mov<0x1B>(v);     // quad_perm [3,2,1,0]
+  else {
+    constexpr int pat = 0x1f | (MASK << 10);
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
     return __hiloint2double(hi, lo);
   }
 }

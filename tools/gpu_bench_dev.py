@@ -36,6 +36,8 @@ if __name__ == '__main__':
             run(1, 14, 16384, meth, 'dense')
             run(2, 4, 16384, meth, 'dense')
             run(2, 5, 4096, meth, 'dense')
+            for nb in (1, 2, 3, 4, 5):
+                run(2, nb, 65536, meth, 'auto')
             run(0, 4, 65536, meth, 'auto')
     if which in ('all', 'c3'):
         run(0, 30, 65536, 'rodas4', 'structured', 0.05, 2.0)
