@@ -1,0 +1,109 @@
+"""Drop-in names of the reference's ``sensitivity/analysis.py`` plus the batched driver that replaces its process pool.
+
+  compute_bound                        sensitivity/analysis.py:20-35
+  define_sensitivity_problem_ds/_rand  sensitivity/analysis.py:38-87
+  _compute_Y                           sensitivity/analysis.py:90-176   (single-array host version; the batched path computes it
+                                                                          on the GPU, fused into the solve kernel)
+  sensitivity_analysis_batch           the numerical core of _sensitivity_analysis (:197-331): sample -> N*(D+1) solves + Y in
+                                       ONE launch -> analyze -> RMSE ranking against data -> best K curves (no plotting)
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .. import config
+from . import morris
+
+
+def compute_bound(value, perturbation=None):
+    perturbation = config.PERTURBATIONS_VALUE if perturbation is None else perturbation
+    if abs(value) < 1e-6:
+        return [0.0, 0.1]
+    lb = value * (1 - perturbation)
+    ub = value * (1 + perturbation)
+    return [max(0.0, lb), ub]
+
+
+def _rand_param_names(num_psites: int):
+    m = (1 << num_psites) - 1
+    return ['A', 'B', 'C', 'D'] + [f'S{i + 1}' for i in range(num_psites)] + [f'D{i + 1}' for i in range(m)]
+
+
+def define_sensitivity_problem_rand(num_psites, values):
+    num_vars = 4 + num_psites + (1 << num_psites) - 1
+    assert len(values) == num_vars, "Length mismatch with values"
+    return {'num_vars': num_vars, 'names': _rand_param_names(num_psites), 'bounds': [compute_bound(v) for v in values]}
+
+
+def define_sensitivity_problem_ds(num_psites, values):
+    num_vars = 4 + 2 * num_psites
+    names = ['A', 'B', 'C', 'D'] + [f'S{i + 1}' for i in range(num_psites)] + [f'D{i + 1}' for i in range(num_psites)]
+    assert len(values) == num_vars, "Length mismatch with values"
+    return {'num_vars': num_vars, 'names': names, 'bounds': [compute_bound(v) for v in values]}
+
+
+def _compute_Y(solution: np.ndarray, num_psites: int, metric: Optional[str] = None) -> float:
+    """Scalar Morris output of ONE solution array (reference signature; Y_METRIC from config unless given)."""
+    metric = config.Y_METRIC if metric is None else metric
+    sub = np.asarray(solution, dtype=float)[:, :2 + num_psites]
+    n_t = sub.shape[0]
+    length = 2 * n_t + n_t * num_psites
+    total = float(sub.sum())
+    if metric == 'total_signal':
+        return total
+    if metric == 'mean_activity':
+        return total / length
+    if metric == 'variance':
+        return float(((sub - total / length) ** 2).sum() / length)
+    if metric == 'dynamics':
+        return float((np.diff(sub, axis=0) ** 2).sum())
+    if metric == 'l2_norm':
+        return math.sqrt(float((sub ** 2).sum()))
+    raise ValueError("Unknown Y_METRIC")
+
+
+def sensitivity_analysis_batch(popt: Sequence[float], time_points, num_psites: int, init_cond, model: Optional[str] = None,
+                               N: Optional[int] = None, num_levels: Optional[int] = None, param_values: Optional[np.ndarray] = None,
+                               pr_data=None, p_data=None, rna_data=None, y_metric: Optional[str] = None, seed: Optional[int] = None,
+                               conf_level: float = 0.99, keep_solutions: bool = True, **solver_kw) -> Dict:
+    """Morris screening around a fitted parameter vector, all solves in one batch on the GPU.
+
+    ``param_values`` may be supplied (e.g. from ``SALib.sample.morris.sample`` with ``local_optimization=True`` as the
+    reference does); otherwise the built-in sampler is used.  Returns a dict with ``Si`` (mu, mu_star, sigma,
+    mu_star_conf, names), ``param_values``, ``Y``, ``status`` and -- if data are given -- ``rmse`` and ``best_idx``
+    (the K = ceil(10 N / num_levels) closest simulations, sensitivity/analysis.py:289-294)."""
+    from .. import batch
+    model = config.ODE_MODEL if model is None else model
+    N = config.NUM_TRAJECTORIES if N is None else int(N)
+    num_levels = config.PARAMETER_SPACE if num_levels is None else int(num_levels)
+    y_metric = config.Y_METRIC if y_metric is None else y_metric
+    popt = np.asarray(popt, dtype=float)
+    problem = (define_sensitivity_problem_rand if model == 'randmod' else define_sensitivity_problem_ds)(num_psites, list(popt))
+    if param_values is None:
+        param_values = morris.sample(problem, N=N, num_levels=num_levels, seed=seed)
+    param_values = np.ascontiguousarray(param_values, dtype=float)
+    res = batch.solve_ode_batch(model, param_values, init_cond, num_psites, time_points, want_sol=keep_solutions, want_flat=False,
+                                metric=y_metric, **solver_kw)
+    Y = res.metric.cpu().numpy()
+    Y = np.nan_to_num(Y, nan=0.0, posinf=0.0, neginf=0.0)             # sensitivity/analysis.py:261
+    Si = morris.analyze(problem, param_values, Y, num_levels=num_levels, conf_level=conf_level, scaled=True, seed=seed)
+    out = {"problem": problem, "Si": Si, "param_values": param_values, "Y": Y, "status": res.status.cpu().numpy()}
+    if keep_solutions:
+        sol = res.sol.cpu().numpy()
+        out["solutions"] = sol
+        if pr_data is not None and p_data is not None and rna_data is not None:
+            n_rna = len(config.TIME_POINTS_RNA)
+            protein_ref = np.asarray(pr_data, float).reshape(-1)
+            psite_ref = np.asarray(p_data, float)
+            rna_ref = np.asarray(rna_data, float).reshape(-1)
+            rna_diff = np.abs(sol[:, -n_rna:, 0] - rna_ref[None, :]) / rna_ref.size
+            psite_diff = np.abs(sol[:, :, 2:2 + num_psites] - psite_ref.T[None, :, :]) / psite_ref.size
+            protein_diff = np.abs(sol[:, :, 1] - protein_ref[None, :]) / protein_ref.size
+            rmse = np.sqrt(((rna_diff ** 2).mean(axis=1) + (psite_diff ** 2).mean(axis=(1, 2)) + (protein_diff ** 2).mean(axis=1)) / 2.0)
+            K = int(np.ceil(N * 10 / num_levels))
+            out["rmse"] = rmse
+            out["best_idx"] = np.argsort(rmse)[:K]
+    return out

@@ -299,3 +299,30 @@ def test_resolvent_form_equals_classical_stage_form(eng, golden_files):
         for o in outs[1:]:
             np.testing.assert_allclose(o, outs[0], rtol=2e-8, atol=2e-10)     # same method, different rounding / step sequences
             assert pm.band_error(o, g["sol_tight"]) <= 0.1
+
+
+def test_morris_driver_and_knockouts_batched(eng, golden_files):
+    """sensitivity_analysis_batch (one launch for N (D+1) solves with the fused Y) and knockout_batch against the oracle."""
+    from phoskintime_amd.sensitivity import sensitivity_analysis_batch
+    from phoskintime_amd.knockout import knockout_batch, _generate_knockout_combinations
+    g, model, n = _load([x for x in golden_files if x.name == "protein_distmod_n4_real.npz"][0])
+    popt, y0 = g["theta"][0], g["y0"][0]
+    out = sensitivity_analysis_batch(popt, g["t"], n, y0, model="distmod", N=12, num_levels=8, seed=4,
+                                     pr_data=np.ones(14), p_data=np.ones((n, 14)), rna_data=np.ones(9))
+    D = popt.size
+    assert out["param_values"].shape == (12 * (D + 1), D) and out["Y"].shape == (12 * (D + 1),)
+    assert not out["status"].any()
+    for i in (0, 5, 77, 12 * (D + 1) - 1):
+        ref = np.clip(pm.solve_exact_lti(model, out["param_values"][i], y0, n, g["t"]), 0, None)
+        assert out["Y"][i] == pytest.approx(pm.compute_Y(ref, n, "total_signal"), rel=2e-6)
+    Si = out["Si"]
+    assert set(("mu", "mu_star", "sigma", "mu_star_conf", "names")) <= set(Si) and len(Si["mu_star"]) == D
+    assert np.isfinite(Si["mu_star"]).all() and (Si["mu_star"] >= 0).all()
+    assert out["best_idx"].size == int(np.ceil(12 * 10 / 8)) and out["rmse"].shape == out["Y"].shape
+    combos, sol, flat = knockout_batch(popt, y0, n, g["t"], model="distmod")
+    assert len(combos) == 4 * (n + 2) == len(_generate_knockout_combinations(n)) and sol.shape == (len(combos), 14, 6)
+    # transcription + translation knocked out, all phosphorylation off: R decays, no new protein, sites only decay
+    k = [i for i, c in enumerate(combos) if c["transcription"] and c["translation"] and c["phosphorylation"] is True][0]
+    th = popt.copy(); th[0] = 0; th[2] = 0; th[4:4 + n] = 0
+    assert pm.band_error(sol[k], np.clip(pm.solve_exact_lti(model, th, y0, n, g["t"]), 0, None)) <= 0.1
+    np.testing.assert_array_equal(sol[0], _np(eng.solve_ode_batch(model, popt[None], y0, n, g["t"]).sol)[0])     # no knock-out

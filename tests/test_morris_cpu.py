@@ -1,0 +1,90 @@
+"""CPU known-answer tests of the Morris sampler / analyser (SALib is absent: SURVEY.md section 8c-4) and of the host-side
+sensitivity helpers against the oracle restatement."""
+import numpy as np
+import pytest
+
+from phoskintime_amd.sensitivity import morris, compute_bound, define_sensitivity_problem_ds, define_sensitivity_problem_rand, _compute_Y
+from oracle import protein_models as pm
+
+
+def _problem(D, lo=0.0, hi=1.0):
+    return {"num_vars": D, "names": [f"x{i}" for i in range(D)], "bounds": [[lo, hi]] * D}
+
+
+def test_sample_structure():
+    D, N, p = 5, 7, 4
+    X = morris.sample(_problem(D, -2.0, 3.0), N, num_levels=p, seed=1)
+    assert X.shape == (N * (D + 1), D)
+    assert X.min() >= -2.0 and X.max() <= 3.0
+    U = (X + 2.0) / 5.0
+    levels = np.arange(p) / (p - 1)
+    assert np.allclose(np.abs(U[:, :, None] - levels[None, None, :]).min(axis=2), 0, atol=1e-12)      # on the level grid
+    T = U.reshape(N, D + 1, D)
+    d = np.diff(T, axis=1)
+    assert ((np.abs(d) > 1e-12).sum(axis=2) == 1).all()                                              # one-at-a-time
+    assert np.allclose(np.abs(d).max(axis=2), p / (2.0 * (p - 1)))                                   # jump = delta
+    moved = np.argmax(np.abs(d), axis=2)
+    assert all(sorted(r) == list(range(D)) for r in moved)                                            # each coordinate once
+    assert np.array_equal(X, morris.sample(_problem(D, -2.0, 3.0), N, num_levels=p, seed=1))          # seeded
+
+
+def test_linear_function_known_answer():
+    D = 6
+    a = np.array([3.0, -2.0, 0.0, 0.5, 10.0, -1.0])
+    prob = _problem(D, 0.0, 2.0)
+    X = morris.sample(prob, 40, num_levels=6, seed=3)
+    Y = X @ a + 7.0
+    Si = morris.analyze(prob, X, Y, num_levels=6, seed=0)
+    # inputs are rescaled to the unit cube: EE_i = a_i * (ub - lb) exactly, sigma = 0
+    np.testing.assert_allclose(Si["mu"], a * 2.0, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Si["mu_star"], np.abs(a) * 2.0, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Si["sigma"], 0.0, atol=1e-10)
+    np.testing.assert_allclose(Si["mu_star_conf"], 0.0, atol=1e-10)
+
+
+def test_product_function_has_interaction_sigma():
+    prob = _problem(3)
+    X = morris.sample(prob, 200, num_levels=4, seed=5)
+    Y = X[:, 0] * X[:, 1] + 0.0 * X[:, 2]
+    Si = morris.analyze(prob, X, Y, num_levels=4, seed=0)
+    assert Si["sigma"][0] > 0.1 and Si["sigma"][1] > 0.1 and Si["sigma"][2] == 0.0 and Si["mu_star"][2] == 0.0
+    assert Si["mu_star_conf"][0] > 0.0
+
+
+def test_hand_made_trajectory():
+    prob = _problem(2)
+    X = np.array([[0.0, 0.0], [2 / 3, 0.0], [2 / 3, 2 / 3]])
+    Y = np.array([1.0, 2.0, 0.0])
+    ee = morris.elementary_effects(prob, X, Y)
+    np.testing.assert_allclose(ee, [[1.5, -3.0]])
+    with pytest.raises(ValueError):
+        morris.elementary_effects(prob, X[:2], Y[:2])
+
+
+def test_scaled_option():
+    prob = _problem(2, 0.0, 4.0)
+    X = morris.sample(prob, 30, num_levels=4, seed=2)
+    Y = 2.0 * X[:, 0] + X[:, 1]
+    raw = morris.analyze(prob, X, Y, seed=0)
+    sc = morris.analyze(prob, X, Y, scaled=True, seed=0)
+    sx = np.std(X / 4.0, axis=0); sy = np.std(Y)
+    np.testing.assert_allclose(sc["mu"], raw["mu"] * sx / sy, rtol=1e-12)
+
+
+def test_bounds_and_problem_definitions_match_oracle():
+    for v in (0.0, 1e-7, 2.0, -2.0, 19.0):
+        assert compute_bound(v) == pm.compute_bound(v)
+    p = define_sensitivity_problem_ds(3, list(np.arange(10.0)))
+    assert p["num_vars"] == 10 and p["names"] == ['A', 'B', 'C', 'D', 'S1', 'S2', 'S3', 'D1', 'D2', 'D3']
+    assert p["bounds"][0] == [0.0, 0.1] and p["bounds"][4] == [2.0, 6.0]
+    pr = define_sensitivity_problem_rand(2, list(np.ones(9)))
+    assert pr["num_vars"] == 9 and pr["names"][-3:] == ['D1', 'D2', 'D3']
+    with pytest.raises(AssertionError):
+        define_sensitivity_problem_ds(3, [1.0] * 9)
+
+
+def test_compute_Y_matches_oracle():
+    rng = np.random.default_rng(0)
+    sol = rng.uniform(0, 3, (14, 9))
+    for metric in pm.METRICS:
+        assert _compute_Y(sol, 4, metric) == pytest.approx(pm.compute_Y(sol, 4, metric), rel=1e-14)
