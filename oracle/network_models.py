@@ -1,0 +1,260 @@
+"""CPU restatement (numpy + SciPy) of the reference's global_model NETWORK right-hand sides and solver call.
+
+TEST INFRASTRUCTURE ONLY (oracle/__init__.py).  Pinned against tests/golden/network_m*.npz, which tools/make_golden_network.py
+produced by running the reference's own classes (Index / System / rhs_odeint / fd_jacobian_odeint / simulate_odeint).
+
+Kinetic topologies (global_model/config.py:59-61):  0 distributive, 1 sequential, 2 combinatorial, 4 saturating.
+State layout (global_model/network.py:28-167): per protein i a block starting at offset_y[i]:
+   models 0/1/4: [R_i, P_i, site_1 .. site_ns]          model 2: [R_i, state_0 (= unphosphorylated) .. state_{2^ns - 1}]
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+from scipy.integrate import odeint
+
+
+@dataclass
+class Network:
+    """Static topology + inputs: everything of System.odeint_args() (network.py:443-526) that does not change per candidate."""
+    model: int
+    N: int
+    n_K: int
+    total_sites: int
+    S: int
+    offset_y: np.ndarray
+    offset_s: np.ndarray
+    n_sites: np.ndarray
+    W_indptr: np.ndarray
+    W_indices: np.ndarray
+    W_data: np.ndarray
+    TF_indptr: np.ndarray
+    TF_indices: np.ndarray
+    TF_data: np.ndarray
+    tf_deg: np.ndarray
+    driver_map: np.ndarray
+    kin_grid: np.ndarray
+    kin_Kmat: np.ndarray
+    n_states: Optional[np.ndarray] = None
+
+    @classmethod
+    def from_npz(cls, g):
+        kw = {k: (int(g[k]) if g[k].ndim == 0 else np.asarray(g[k])) for k in
+              ("model", "N", "n_K", "total_sites", "S", "offset_y", "offset_s", "n_sites", "W_indptr", "W_indices", "W_data",
+               "TF_indptr", "TF_indices", "TF_data", "tf_deg", "driver_map", "kin_grid", "kin_Kmat")}
+        if "n_states" in g:
+            kw["n_states"] = np.asarray(g["n_states"])
+        return cls(**kw)
+
+
+@dataclass
+class Params:
+    """One candidate's physical parameters (System.update, network.py:293-302)."""
+    c_k: np.ndarray
+    A_i: np.ndarray
+    B_i: np.ndarray
+    C_i: np.ndarray
+    D_i: np.ndarray
+    Dp_i: np.ndarray
+    E_i: np.ndarray
+    tf_scale: float
+
+    @classmethod
+    def from_npz(cls, g, k):
+        return cls(*(np.asarray(g[n][k]) for n in ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i")), float(g["tf_scale"][k]))
+
+
+def time_bucket(t, grid):
+    """global_model/utils.py:211-225 and jacspeedup.py:149-172 (kin_eval_step): column searchsorted(grid, t, 'right') - 1, clamped."""
+    if t <= grid[0]:
+        return 0
+    if t >= grid[-1]:
+        return grid.size - 1
+    j = int(np.searchsorted(grid, t, side="right")) - 1
+    return min(max(j, 0), grid.size - 1)
+
+
+def calculate_synthesis_rate(Ai, tf_scale, u_raw):
+    """global_model/models.py:28-65."""
+    u = u_raw / (1.0 + abs(u_raw))
+    if u >= 0.0:
+        return Ai * (1.0 + (tf_scale * u) / (1.0 + u + 1e-6))
+    return Ai / (1.0 + tf_scale * abs(u))
+
+
+def csr_matvec(indptr, indices, data, x, n_rows):
+    """jacspeedup.py:71-98."""
+    out = np.zeros(n_rows)
+    for i in range(n_rows):
+        s = 0.0
+        for p in range(indptr[i], indptr[i + 1]):
+            s += data[p] * x[indices[p]]
+        out[i] = s
+    return out
+
+
+def site_rates(net: Network, p: Params, t):
+    """S_all = W (K(t) * c_k)  -- jacspeedup.py:198-204; for model 2 the same numbers come from S_cache[:, bucket]
+    (build_S_cache_into, jacspeedup.py:117-145)."""
+    jb = time_bucket(t, net.kin_grid)
+    Kt = net.kin_Kmat[:, jb] * p.c_k
+    if net.model == 2:
+        out = np.zeros(net.total_sites)
+        for i in range(net.total_sites):
+            s = 0.0
+            for q in range(net.W_indptr[i], net.W_indptr[i + 1]):
+                k = net.W_indices[q]
+                s += net.W_data[q] * (net.kin_Kmat[k, jb] * p.c_k[k])
+            out[i] = s
+        return out, Kt
+    return csr_matvec(net.W_indptr, net.W_indices, net.W_data, Kt, net.total_sites), Kt
+
+
+def tf_inputs(net: Network, p: Params, y, Kt):
+    """P_vec (driven proteins read K(t) c_k; model 2 ignores driver_map, jacspeedup.py:319-327) -> TF CSR matvec -> / tf_deg ->
+    first squash (models 0/1/2: jacspeedup.py:225-228; model 4 leaves it to the kernel, :371-373)."""
+    P_vec = np.zeros(net.N)
+    for i in range(net.N):
+        st = net.offset_y[i]
+        if net.model == 2:
+            tot = 0.0
+            for m in range(int(net.n_states[i])):
+                tot += y[st + 1 + m]
+            P_vec[i] = tot
+        else:
+            d = net.driver_map[i]
+            if d >= 0:
+                P_vec[i] = Kt[d]
+            else:
+                tot = y[st + 1]
+                for j in range(int(net.n_sites[i])):
+                    tot += y[st + 2 + j]
+                P_vec[i] = tot
+    TF_in = csr_matvec(net.TF_indptr, net.TF_indices, net.TF_data, P_vec, net.N)
+    for i in range(net.N):
+        val = TF_in[i] / net.tf_deg[i]
+        TF_in[i] = val if net.model == 4 else val / (1.0 + abs(val))
+    return TF_in
+
+
+def rhs(net: Network, p: Params, y, t):
+    """rhs_odeint (jacspeedup.py:392-394) for the four topologies: models.py:150-212 (0), :216-306 (1), :323-432 (2), :72-146 (4)."""
+    y = np.asarray(y, float)
+    dy = np.zeros_like(y)
+    S_all, Kt = site_rates(net, p, t)
+    TF_in = tf_inputs(net, p, y, Kt)
+    for i in range(net.N):
+        st = int(net.offset_y[i]); ss = int(net.offset_s[i]); ns = int(net.n_sites[i])
+        R = y[st]
+        Ai, Bi, Ci, Di, Ei = p.A_i[i], p.B_i[i], p.C_i[i], p.D_i[i], p.E_i[i]
+        synth = calculate_synthesis_rate(Ai, p.tf_scale, TF_in[i])
+        dy[st] = synth - Bi * R
+        if net.model == 0:
+            P = y[st + 1]
+            if ns == 0:
+                dy[st + 1] = Ci * R - Di * P
+            else:
+                sum_S = 0.0; sum_back = 0.0
+                for j in range(ns):
+                    s_rate = S_all[ss + j]; ps = y[st + 2 + j]
+                    sum_S += s_rate; sum_back += Ei * ps
+                    dy[st + 2 + j] = s_rate * P - (Ei + p.Dp_i[ss + j] + Di) * ps
+                dy[st + 1] = Ci * R - (Di + sum_S) * P + sum_back
+        elif net.model == 4:
+            P = y[st + 1]
+            trans = (Ci * R) / (1.0 + R)
+            if ns == 0:
+                dy[st + 1] = trans - Di * P
+            else:
+                sum_f = 0.0; sum_b = 0.0
+                for j in range(ns):
+                    ps = y[st + 2 + j]
+                    fwd = (S_all[ss + j] * P) / (1.0 + P)
+                    back = Ei * ps
+                    sum_f += fwd; sum_b += back
+                    dy[st + 2 + j] = fwd - (p.Dp_i[ss + j] + Di) * ps - back
+                dy[st + 1] = trans - Di * P - sum_f + sum_b
+        elif net.model == 1:
+            P0 = y[st + 1]
+            if ns == 0:
+                dy[st + 1] = Ci * R - Di * P0
+                continue
+            base = st + 2
+            k0 = S_all[ss]; P1 = y[base]
+            dy[st + 1] = Ci * R - Di * P0 - k0 * P0 + Ei * P1
+            if ns == 1:
+                dy[base] = k0 * P0 - (Ei + p.Dp_i[ss] + Di) * P1
+                continue
+            k1 = S_all[ss + 1]; P2 = y[base + 1]
+            dy[base] = k0 * P0 + Ei * P2 - (k1 + Ei + p.Dp_i[ss] + Di) * P1
+            for j in range(1, ns - 1):
+                ix = base + j
+                dy[ix] = S_all[ss + j] * y[ix - 1] + Ei * y[ix + 1] - (S_all[ss + j + 1] + Ei + p.Dp_i[ss + j] + Di) * y[ix]
+            il = base + ns - 1
+            dy[il] = S_all[ss + ns - 1] * y[il - 1] - (Ei + p.Dp_i[ss + ns - 1] + Di) * y[il]
+        else:  # model 2
+            if ns == 0:
+                dy[st + 1] = Ci * R - Di * y[st + 1]
+                continue
+            base = st + 1
+            nst = int(net.n_states[i])
+            dy[base] += Ci * R
+            dy[base] += -Di * y[base]
+            for m in range(1, nst):
+                Pm = y[base + m]
+                if Pm == 0.0:
+                    continue
+                mm = m; dp_rate = 0.0
+                while mm != 0:
+                    lsb = mm & -mm
+                    mm -= lsb
+                    j = lsb.bit_length() - 1
+                    flux = Ei * Pm
+                    dy[base + m] -= flux
+                    dy[base + (m ^ lsb)] += flux
+                    dp_rate += p.Dp_i[ss + j] + Di
+                dy[base + m] -= dp_rate * Pm
+            for m in range(nst):                       # build_random_transitions order (models.py:435-485): m ascending, j ascending
+                for j in range(ns):
+                    if (m & (1 << j)) == 0:
+                        flux = S_all[ss + j] * y[base + m]
+                        dy[base + m] -= flux
+                        dy[base + (m | (1 << j))] += flux
+    return dy
+
+
+def fd_jacobian(net: Network, p: Params, y, t, eps=1e-8):
+    """jacspeedup.py:398-588 (fd_jacobian_nb_core_*): forward differences, h = eps * max(1, |y_j|), J row-major."""
+    y = np.asarray(y, float)
+    n = y.size
+    J = np.empty((n, n))
+    f0 = rhs(net, p, y, t)
+    for j in range(n):
+        yp = y.copy()
+        aj = y[j]
+        h = eps * (1.0 if abs(aj) < 1.0 else abs(aj))
+        yp[j] = aj + h
+        J[:, j] = (rhs(net, p, yp, t) - f0) * (1.0 / h)
+    return J
+
+
+def default_y0(net: Network):
+    """System.y0 (network.py:421-441): R = 1, P = 1 (state_0 = 1), phospho states 0.01."""
+    y = np.zeros(net.S)
+    for i in range(net.N):
+        st = int(net.offset_y[i])
+        y[st] = 1.0
+        y[st + 1] = 1.0
+        nrest = (int(net.n_states[i]) - 1) if net.model == 2 else int(net.n_sites[i])
+        y[st + 2: st + 2 + nrest] = 0.01
+    return y
+
+
+def simulate_odeint(net: Network, p: Params, t_eval, rtol, atol, mxstep, y0=None, use_fd_jac=True):
+    """simulate.py:34-80: odeint(rhs_odeint, y0, t, Dfun=fd_jacobian_odeint, col_deriv=False, rtol, atol, mxstep)."""
+    y0 = default_y0(net) if y0 is None else np.asarray(y0, float)
+    f = lambda y, t: rhs(net, p, y, t)
+    kw = dict(Dfun=(lambda y, t: fd_jacobian(net, p, y, t)), col_deriv=False) if use_fd_jac else {}
+    return np.ascontiguousarray(odeint(f, y0, np.asarray(t_eval, float), rtol=rtol, atol=atol, mxstep=mxstep, **kw))

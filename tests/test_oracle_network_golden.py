@@ -1,0 +1,51 @@
+"""CPU: the network oracle (oracle/network_models.py) against golden vectors produced by running the reference's
+global_model classes (tools/make_golden_network.py): RHS and finite-difference Jacobian bit for bit, LSODA trajectories."""
+import numpy as np
+import pytest
+
+from oracle import network_models as nm
+from pathlib import Path
+
+GOLD = sorted((Path(__file__).resolve().parent / "golden").glob("network_m*.npz"))
+
+
+def test_inventory():
+    names = {f.name for f in GOLD}
+    for m in (0, 1, 2, 4):
+        assert f"network_m{m}_small.npz" in names and f"network_m{m}_medium.npz" in names
+
+
+@pytest.mark.parametrize("f", GOLD, ids=lambda f: f.stem)
+def test_rhs_and_fd_jacobian_bit_exact(f):
+    g = np.load(f); net = nm.Network.from_npz(g)
+    np.testing.assert_array_equal(nm.default_y0(net), g["y0"])
+    ks = range(4) if net.S < 60 else range(2)
+    for k in ks:
+        p = nm.Params.from_npz(g, k)
+        for ti, t in enumerate(g["t_probe"]):
+            np.testing.assert_array_equal(nm.rhs(net, p, g["y0"], t), g["rhs_y0"][k, ti])
+            np.testing.assert_array_equal(nm.rhs(net, p, g["y_rand"][k], t), g["rhs_rand"][k, ti])
+    if net.S < 60:
+        p = nm.Params.from_npz(g, 0)
+        np.testing.assert_array_equal(nm.fd_jacobian(net, p, g["y_rand"][0], float(g["fd_jac_t"])), g["fd_jac"][0])
+
+
+@pytest.mark.parametrize("f", [x for x in GOLD if "small" in x.name], ids=lambda f: f.stem)
+def test_simulate_odeint_reproduces_reference(f):
+    """Same SciPy LSODA, same RHS, same finite-difference Dfun => the same trajectory (bit for bit)."""
+    g = np.load(f); net = nm.Network.from_npz(g)
+    p = nm.Params.from_npz(g, 1)
+    Y = nm.simulate_odeint(net, p, g["t_eval"], 1e-8, 1e-8, 200000)
+    np.testing.assert_array_equal(Y, g["Y_lsoda8"][1])
+
+
+def test_time_bucket_edges():
+    grid = np.array([0.0, 0.5, 0.75, 1.0, 2.0])
+    assert [nm.time_bucket(t, grid) for t in (-1.0, 0.0, 0.3, 0.5, 0.74, 0.75, 1.9, 2.0, 9.0)] == [0, 0, 0, 1, 1, 2, 3, 4, 4]
+
+
+def test_synthesis_rate_branches():
+    assert nm.calculate_synthesis_rate(2.0, 3.0, 0.0) == 2.0
+    u = 0.5 / 1.5
+    assert nm.calculate_synthesis_rate(2.0, 3.0, 0.5) == 2.0 * (1.0 + (3.0 * u) / (1.0 + u + 1e-6))
+    assert nm.calculate_synthesis_rate(2.0, 3.0, -0.5) == 2.0 / (1.0 + 3.0 * u)
