@@ -124,6 +124,43 @@ int pk_rhs_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
 int pk_jacobian_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
                                    const double* theta, double* J);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Network (global_model) path -- SURVEY.md section 8 rows a9-a16, a21, a23.
+ * pk_network_desc mirrors what global_model.network.System.odeint_args() packs (network.py:443-526) minus the per-candidate
+ * parameters; all pointers are HOST pointers and are copied to HBM by pk_network_create.
+ * A candidate is one row of x [B, n_var], n_var = n_K + 5 N + total_sites + 1, laid out as the optimiser's decision vector
+ * (global_model/params.py:60-96):  [c_k | A_i | B_i | C_i | D_i | Dp_i | E_i | tf_scale];  x_is_raw != 0 applies the softplus of
+ * params.unpack_params (params.py:106-132, utils.py:229-241) on load.
+ * State layout: per protein i at offset_y[i]: models 0/1/4 [R, P, site_1..site_ns]; model 2 [R, state_0 .. state_{2^ns - 1}]. */
+typedef struct pk_network_desc {
+  int32_t model;                 /* 0 distributive, 1 sequential, 2 combinatorial, 4 saturating (global_model/config.py:59-61) */
+  int32_t N, n_K, total_sites, n_grid;
+  const int32_t *offset_y, *offset_s, *n_sites;                        /* [N] */
+  const int32_t *W_indptr, *W_indices; const double* W_data;           /* CSR, total_sites x n_K  (kinase -> site) */
+  const int32_t *TF_indptr, *TF_indices; const double* TF_data;        /* CSR, N x N              (TF -> target)   */
+  const double*  tf_deg;                                               /* [N] */
+  const int32_t* driver_map;                                           /* [N] kinase index driving protein i, or -1 */
+  const double*  kin_grid;                                             /* [n_grid] bucket edges of the kinase input */
+  const double*  kin_Kmat;                                             /* [n_K, n_grid] row-major */
+} pk_network_desc;
+typedef struct pk_net pk_net;
+
+pk_net* pk_network_create(pk_ctx*, const pk_network_desc*);            /* NULL on error: see pk_last_error */
+void    pk_network_destroy(pk_net*);
+int     pk_network_n_states(const pk_net*);
+int     pk_network_n_var(const pk_net*);
+
+/* Replaces global_model.jacspeedup.rhs_odeint(y, t, *args) (jacspeedup.py:392-394 -> rhs_nb_* :176-388) for B candidates:
+ * x [B,n_var]; y [S] or [B,S]; t [1] or [B] (device pointers); dydt [B,S]. */
+int pk_network_rhs_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y, int y_is_batched,
+                         const double* t, int t_is_batched, double* dydt);
+/* Analytic Jacobian, row-major [B,S,S]; stands where the reference uses the finite-difference fd_jacobian_odeint
+ * (jacspeedup.py:398-588) as odeint's Dfun. */
+int pk_network_jacobian_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y, int y_is_batched,
+                              const double* t, int t_is_batched, double* J);
+/* global_model.params.unpack_params (softplus of the raw decision vectors): x_raw [B,n_var] -> x_phys [B,n_var]. */
+int pk_network_unpack_batch(pk_ctx*, pk_net*, int64_t B, const double* x_raw, double* x_phys);
+
 /* Timing hook for bench.py: runs `iters` back-to-back launches of pk_solve_protein_batch on the context's
  * stream between two hipEvents and returns the mean kernel time per launch in milliseconds (< 0 on error). */
 double pk_time_solve_protein_batch(pk_ctx*, int iters, int model, int n_sites, int64_t B,

@@ -31,6 +31,15 @@ class PhoskinError(RuntimeError):
     pass
 
 
+class NetworkDesc(C.Structure):
+    """Mirror of ``pk_network_desc`` (include/phoskin.h)."""
+    _fields_ = [("model", C.c_int32), ("N", C.c_int32), ("n_K", C.c_int32), ("total_sites", C.c_int32), ("n_grid", C.c_int32),
+                ("offset_y", C.c_void_p), ("offset_s", C.c_void_p), ("n_sites", C.c_void_p),
+                ("W_indptr", C.c_void_p), ("W_indices", C.c_void_p), ("W_data", C.c_void_p),
+                ("TF_indptr", C.c_void_p), ("TF_indices", C.c_void_p), ("TF_data", C.c_void_p),
+                ("tf_deg", C.c_void_p), ("driver_map", C.c_void_p), ("kin_grid", C.c_void_p), ("kin_Kmat", C.c_void_p)]
+
+
 class SolverOpts(C.Structure):
     """Mirror of ``pk_solver_opts`` (include/phoskin.h)."""
     _fields_ = [("method", C.c_int32), ("linsolve", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double),
@@ -45,6 +54,8 @@ SYMBOLS = (
     "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch",
     "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
     "pk_time_solve_protein_batch",
+    "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
+    "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch",
 )
 
 _lib = None
@@ -83,6 +94,13 @@ def load():
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, i32, i32, i64, vp, vp, vp]
     for f in ("pk_jacobian_protein_batch", "pk_jacobian_protein_batch_host"):
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, i32, i32, i64, vp, vp]
+    lib.pk_network_create.restype = vp; lib.pk_network_create.argtypes = [vp, C.POINTER(NetworkDesc)]
+    lib.pk_network_destroy.restype = None; lib.pk_network_destroy.argtypes = [vp]
+    lib.pk_network_n_states.restype = i32; lib.pk_network_n_states.argtypes = [vp]
+    lib.pk_network_n_var.restype = i32; lib.pk_network_n_var.argtypes = [vp]
+    for f in ("pk_network_rhs_batch", "pk_network_jacobian_batch"):
+        getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, vp]
+    lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
     lib.pk_time_solve_protein_batch.restype = dbl
     lib.pk_time_solve_protein_batch.argtypes = [vp, i32] + solve_args[1:]
     _lib = lib

@@ -103,6 +103,11 @@ void pk_destroy(pk_ctx* c) {
 
 const char* pk_last_error(pk_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// accessors for the other translation units (pk_network.hip)
+int pk_ctx_device(pk_ctx* c) { return c->device; }
+void* pk_ctx_stream(pk_ctx* c) { return (void*)c->stream; }
+int pk_ctx_fail(pk_ctx* c, int code, const char* msg) { return fail(c, code, msg ? msg : ""); }
+
 int pk_set_stream(pk_ctx* c, void* s) {
   if (!c) return PK_ERR_ARG;
   c->stream = (hipStream_t)s;

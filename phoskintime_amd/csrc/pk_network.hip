@@ -1,0 +1,202 @@
+// pk_network.hip -- kernels and C ABI of the network (global_model) path: batched RHS, analytic Jacobian, softplus unpack.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/phoskin.h"
+#include "pk_network.hpp"
+
+struct pk_ctx;                                   // defined in pk_capi.hip
+extern "C" int pk_ctx_device(pk_ctx*);
+extern "C" void* pk_ctx_stream(pk_ctx*);
+extern "C" int pk_ctx_fail(pk_ctx*, int code, const char* msg);
+
+namespace pk {
+
+// dydt[b, :] = f(t_b, y_b; x_b)
+__global__ __launch_bounds__(256) void net_rhs_kernel(const NetDev n, const double* __restrict__ x, const int x_is_raw,
+                                                      const double* __restrict__ y, const int y_batched,
+                                                      const double* __restrict__ t, const int t_batched, double* __restrict__ dydt) {
+  extern __shared__ __align__(16) double lds[];
+  const NetLds L(lds, n);
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const double* xb = x + b * n.n_var;
+  for (int k = tid; k < n.n_var; k += nt) L.p[k] = x_is_raw ? softplus(xb[k]) : xb[k];
+  const double* yb = y + (y_batched ? b * n.S : 0);
+  for (int k = tid; k < n.S; k += nt) L.y[k] = yb[k];
+  const int jb = net_bucket(t[t_batched ? b : 0], n.kin_grid, n.n_grid);
+  __syncthreads();
+  net_prepare<false>(n, L, jb);
+  for (int k = tid; k < n.S; k += nt) dydt[b * n.S + k] = net_state_rhs(n, L, k);
+}
+
+// J[b, r, c] = d f_r / d y_c, row-major, analytic
+__global__ __launch_bounds__(256) void net_jac_kernel(const NetDev n, const double* __restrict__ x, const int x_is_raw,
+                                                      const double* __restrict__ y, const int y_batched,
+                                                      const double* __restrict__ t, const int t_batched, double* __restrict__ J) {
+  extern __shared__ __align__(16) double lds[];
+  const NetLds L(lds, n);
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const double* xb = x + b * n.n_var;
+  for (int k = tid; k < n.n_var; k += nt) L.p[k] = x_is_raw ? softplus(xb[k]) : xb[k];
+  const double* yb = y + (y_batched ? b * n.S : 0);
+  for (int k = tid; k < n.S; k += nt) L.y[k] = yb[k];
+  const int jb = net_bucket(t[t_batched ? b : 0], n.kin_grid, n.n_grid);
+  __syncthreads();
+  net_prepare<true>(n, L, jb);
+  double* Jb = J + b * (size_t)n.S * n.S;
+  // block-diagonal part: one thread per row, its protein's columns; everything else zero
+  for (int r = tid; r < n.S; r += nt) {
+    double* row = Jb + (size_t)r * n.S;
+    for (int c = 0; c < n.S; ++c) row[c] = 0.0;
+    const int i = n.state_prot[r], lr = n.state_local[r];
+    const int st = n.offset_y[i];
+    const int cnt = (n.model == 2) ? 1 + (1 << n.n_sites[i]) : 2 + n.n_sites[i];
+    for (int lc = 0; lc < cnt; ++lc) row[st + lc] = net_block_jac(n, L, i, lr, lc);
+    if (lr == 0) {
+      // TF coupling of the mRNA row: d synth_i / d y_c = dsyn_i * TF_ij * [c is a protein-form state of an undriven regulator j]
+      for (int q = n.TF_indptr[i]; q < n.TF_indptr[i + 1]; ++q) {
+        const int j = n.TF_indices[q];
+        if (n.model != 2 && n.driver_map[j] >= 0) continue;
+        const double w = L.dsyn[i] * n.TF_data[q];
+        const int sj = n.offset_y[j];
+        const int cj = (n.model == 2) ? (1 << n.n_sites[j]) : 1 + n.n_sites[j];
+        for (int m = 0; m < cj; ++m) row[sj + 1 + m] += w;
+      }
+    }
+  }
+}
+
+__global__ void net_unpack_kernel(const double* __restrict__ x, double* __restrict__ out, const long long total) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < total) out[k] = softplus(x[k]);
+}
+
+}  // namespace pk
+
+struct pk_net {
+  pk::NetDev d;
+  std::vector<void*> allocs;
+  size_t lds_bytes;
+};
+
+namespace {
+template <class T>
+const T* upload(pk_net* n, const T* host, size_t count, bool& ok) {
+  if (!ok) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, (count ? count : 1) * sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
+  n->allocs.push_back(p);
+  if (count && hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { ok = false; return nullptr; }
+  return (const T*)p;
+}
+}  // namespace
+
+extern "C" {
+
+pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
+  if (!c || !d) return nullptr;
+  if (!(d->model == 0 || d->model == 1 || d->model == 2 || d->model == 4)) { pk_ctx_fail(c, PK_ERR_ARG, "network model must be 0, 1, 2 or 4"); return nullptr; }
+  if (d->N < 1 || d->n_K < 1 || d->total_sites < 0 || d->n_grid < 1) { pk_ctx_fail(c, PK_ERR_ARG, "bad network dimensions"); return nullptr; }
+  if (!d->offset_y || !d->offset_s || !d->n_sites || !d->W_indptr || !d->TF_indptr || !d->tf_deg || !d->driver_map || !d->kin_grid || !d->kin_Kmat) {
+    pk_ctx_fail(c, PK_ERR_ARG, "null array in pk_network_desc"); return nullptr;
+  }
+  // validate the layout on the host: a wrong offset would become an out-of-bounds access on the GPU
+  int S = 0, sites = 0;
+  std::vector<int32_t> sp, sl;
+  for (int i = 0; i < d->N; ++i) {
+    const int ns = d->n_sites[i];
+    if (ns < 0 || (d->model == 2 && ns > 10)) { pk_ctx_fail(c, PK_ERR_ARG, "n_sites out of range (model 2: <= 10)"); return nullptr; }
+    if (d->offset_y[i] != S || d->offset_s[i] != sites) { pk_ctx_fail(c, PK_ERR_ARG, "offset_y / offset_s are not the running sums of the block sizes"); return nullptr; }
+    const int cnt = (d->model == 2) ? 1 + (1 << ns) : 2 + ns;
+    for (int l = 0; l < cnt; ++l) { sp.push_back(i); sl.push_back(l); }
+    S += cnt; sites += ns;
+    if (d->driver_map[i] >= d->n_K) { pk_ctx_fail(c, PK_ERR_ARG, "driver_map entry >= n_K"); return nullptr; }
+  }
+  if (sites != d->total_sites) { pk_ctx_fail(c, PK_ERR_ARG, "sum(n_sites) != total_sites"); return nullptr; }
+  if (d->W_indptr[0] != 0 || d->TF_indptr[0] != 0) { pk_ctx_fail(c, PK_ERR_ARG, "CSR indptr must start at 0"); return nullptr; }
+  for (int r = 0; r < sites; ++r) if (d->W_indptr[r + 1] < d->W_indptr[r]) { pk_ctx_fail(c, PK_ERR_ARG, "W_indptr not monotone"); return nullptr; }
+  for (int r = 0; r < d->N; ++r) if (d->TF_indptr[r + 1] < d->TF_indptr[r]) { pk_ctx_fail(c, PK_ERR_ARG, "TF_indptr not monotone"); return nullptr; }
+  const int nnzW = d->W_indptr[sites], nnzT = d->TF_indptr[d->N];
+  for (int q = 0; q < nnzW; ++q) if (d->W_indices[q] < 0 || d->W_indices[q] >= d->n_K) { pk_ctx_fail(c, PK_ERR_ARG, "W_indices out of range"); return nullptr; }
+  for (int q = 0; q < nnzT; ++q) if (d->TF_indices[q] < 0 || d->TF_indices[q] >= d->N) { pk_ctx_fail(c, PK_ERR_ARG, "TF_indices out of range"); return nullptr; }
+  for (int g = 1; g < d->n_grid; ++g) if (!(d->kin_grid[g] > d->kin_grid[g - 1])) { pk_ctx_fail(c, PK_ERR_ARG, "kin_grid must increase"); return nullptr; }
+
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return nullptr;
+  pk_net* n = new pk_net();
+  bool ok = true;
+  pk::NetDev& v = n->d;
+  v.model = d->model; v.N = d->N; v.n_K = d->n_K; v.sites = sites; v.S = S; v.n_grid = d->n_grid; v.n_var = d->n_K + 5 * d->N + sites + 1;
+  v.offset_y = upload(n, d->offset_y, d->N, ok); v.offset_s = upload(n, d->offset_s, d->N, ok); v.n_sites = upload(n, d->n_sites, d->N, ok);
+  v.state_prot = upload(n, sp.data(), sp.size(), ok); v.state_local = upload(n, sl.data(), sl.size(), ok);
+  v.W_indptr = upload(n, d->W_indptr, sites + 1, ok); v.W_indices = upload(n, d->W_indices, nnzW, ok); v.W_data = upload(n, d->W_data, nnzW, ok);
+  v.TF_indptr = upload(n, d->TF_indptr, d->N + 1, ok); v.TF_indices = upload(n, d->TF_indices, nnzT, ok); v.TF_data = upload(n, d->TF_data, nnzT, ok);
+  v.tf_deg = upload(n, d->tf_deg, d->N, ok); v.driver_map = upload(n, d->driver_map, d->N, ok);
+  v.kin_grid = upload(n, d->kin_grid, d->n_grid, ok); v.kin_Kmat = upload(n, d->kin_Kmat, (size_t)d->n_K * d->n_grid, ok);
+  n->lds_bytes = ((size_t)v.n_var + v.S + v.n_K + v.sites + 3 * (size_t)v.N) * sizeof(double);
+  if (!ok || n->lds_bytes > 160 * 1024) {
+    pk_ctx_fail(c, ok ? PK_ERR_UNSUPPORTED : PK_ERR_NOMEM, ok ? "network too large for one workgroup's LDS (160 KiB)" : "hipMalloc / hipMemcpy failed");
+    pk_network_destroy(n);
+    return nullptr;
+  }
+  if (n->lds_bytes > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)pk::net_rhs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)pk::net_jac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->lds_bytes);
+  }
+  return n;
+}
+
+void pk_network_destroy(pk_net* n) {
+  if (!n) return;
+  for (void* p : n->allocs) (void)hipFree(p);
+  delete n;
+}
+
+int pk_network_n_states(const pk_net* n) { return n ? n->d.S : PK_ERR_ARG; }
+int pk_network_n_var(const pk_net* n) { return n ? n->d.n_var : PK_ERR_ARG; }
+
+static int net_args_ok(pk_ctx* c, pk_net* n, int64_t B, const void* x, const void* y, const void* t, const void* out) {
+  if (!c || !n) return PK_ERR_ARG;
+  if (B < 0) return pk_ctx_fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (B > 0 && (!x || !y || !t || !out)) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
+  return PK_OK;
+}
+
+int pk_network_rhs_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y, int y_is_batched,
+                         const double* t, int t_is_batched, double* dydt) {
+  int rc = net_args_ok(c, n, B, x, y, t, dydt);
+  if (rc || B == 0) return rc;
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
+  hipLaunchKernelGGL(pk::net_rhs_kernel, dim3((unsigned)B), dim3(256), n->lds_bytes, (hipStream_t)pk_ctx_stream(c), n->d, x, x_is_raw, y,
+                     y_is_batched, t, t_is_batched, dydt);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+int pk_network_jacobian_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y, int y_is_batched,
+                              const double* t, int t_is_batched, double* J) {
+  int rc = net_args_ok(c, n, B, x, y, t, J);
+  if (rc || B == 0) return rc;
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
+  hipLaunchKernelGGL(pk::net_jac_kernel, dim3((unsigned)B), dim3(256), n->lds_bytes, (hipStream_t)pk_ctx_stream(c), n->d, x, x_is_raw, y,
+                     y_is_batched, t, t_is_batched, J);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+int pk_network_unpack_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x_raw, double* x_phys) {
+  if (!c || !n) return PK_ERR_ARG;
+  if (B < 0) return pk_ctx_fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (B == 0) return PK_OK;
+  if (!x_raw || !x_phys) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  const long long total = (long long)B * n->d.n_var;
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
+  hipLaunchKernelGGL(pk::net_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)pk_ctx_stream(c), x_raw, x_phys, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+}  // extern "C"

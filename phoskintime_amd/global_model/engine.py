@@ -1,0 +1,150 @@
+"""``NetworkEngine``: the static network of a reference ``System`` (global_model/network.py:199-526) resident in HBM, plus
+batched evaluation of candidates through the C ABI (``pk_network_*``, include/phoskin.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _capi
+from ..batch import get_context, _dev_f64, _ptr
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class NetworkEngine:
+    """Device-resident topology + kinase input of one network.  Candidates are rows ``x`` of length ``n_var`` =
+    ``n_K + 5 N + total_sites + 1`` = ``[c_k | A_i | B_i | C_i | D_i | Dp_i | E_i | tf_scale]`` (params.py:60-96)."""
+
+    def __init__(self, model: int, offset_y, offset_s, n_sites, W_indptr, W_indices, W_data, TF_indptr, TF_indices, TF_data,
+                 tf_deg, driver_map, kin_grid, kin_Kmat, device: Optional[int] = None):
+        self.ctx = get_context(device)
+        self.model = int(model)
+        self._keep = [_i32(offset_y), _i32(offset_s), _i32(n_sites), _i32(W_indptr), _i32(W_indices), _f64(W_data),
+                      _i32(TF_indptr), _i32(TF_indices), _f64(TF_data), _f64(tf_deg), _i32(driver_map), _f64(kin_grid), _f64(kin_Kmat)]
+        (oy, os_, ns, wp, wi, wd, tp, ti, td, deg, drv, grid, kmat) = self._keep
+        self.N = int(oy.size); self.n_K = int(kmat.shape[0]); self.total_sites = int(ns.sum()); self.n_grid = int(grid.size)
+        if kmat.shape != (self.n_K, self.n_grid):
+            raise ValueError("kin_Kmat must be [n_K, n_grid]")
+        d = _capi.NetworkDesc(self.model, self.N, self.n_K, self.total_sites, self.n_grid,
+                              *(a.ctypes.data for a in (oy, os_, ns, wp, wi, wd, tp, ti, td, deg, drv, grid, kmat)))
+        self._h = self.ctx.lib.pk_network_create(self.ctx.handle, C.byref(d))
+        if not self._h:
+            raise _capi.PhoskinError("pk_network_create failed: " + (self.ctx.lib.pk_last_error(self.ctx.handle) or b"").decode())
+        self.S = self.ctx.lib.pk_network_n_states(self._h)
+        self.n_var = self.ctx.lib.pk_network_n_var(self._h)
+
+    # ------------------------------------------------------------------ constructors from reference objects
+    @classmethod
+    def from_system(cls, sys, model: int, device: Optional[int] = None):
+        """From a reference ``global_model.network.System`` (duck-typed: only its array attributes are read)."""
+        drv = np.full(sys.idx.N, -1, dtype=np.int32)                 # network.py:454-469
+        for k_name in sys.idx.kinases:
+            if k_name in sys.idx.p2i:
+                drv[sys.idx.p2i[k_name]] = sys.idx.k2i[k_name]
+        for orphan, proxy in getattr(sys.idx, "proxy_map", {}).items():
+            if orphan in sys.idx.p2i:
+                drv[sys.idx.p2i[orphan]] = sys.idx.k2i[proxy]
+        return cls(model, sys.idx.offset_y, sys.idx.offset_s, sys.idx.n_sites, sys.W_indptr, sys.W_indices, sys.W_data,
+                   sys.TF_indptr, sys.TF_indices, sys.TF_data, sys.tf_deg, drv, sys.kin_grid, sys.kin_Kmat, device)
+
+    @classmethod
+    def from_odeint_args(cls, args: Sequence, model: int, device: Optional[int] = None):
+        """From the 23-tuple ``System.odeint_args()`` of models 0 / 1 / 4 (network.py:508-526)."""
+        if model == 2:
+            raise ValueError("model 2's odeint_args carry S_cache instead of W / kin_Kmat: use from_system")
+        (c_k, A, B, Cc, D, Dp, E, tfs, grid, kmat, wp, wi, wd, nW, tp, ti, td, nT, oy, os_, ns, deg, drv) = args
+        return cls(model, oy, os_, ns, wp, wi, wd, tp, ti, td, deg, drv, grid, kmat, device)
+
+    @classmethod
+    def from_npz(cls, g, device: Optional[int] = None):
+        return cls(int(g["model"]), g["offset_y"], g["offset_s"], g["n_sites"], g["W_indptr"], g["W_indices"], g["W_data"],
+                   g["TF_indptr"], g["TF_indices"], g["TF_data"], g["tf_deg"], g["driver_map"], g["kin_grid"], g["kin_Kmat"], device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.pk_network_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ candidates
+    def pack_params(self, c_k, A_i, B_i, C_i, D_i, Dp_i, E_i, tf_scale) -> np.ndarray:
+        """Physical parameters in ``System.update`` order (network.py:293-302) -> one candidate row."""
+        x = np.concatenate([np.ravel(c_k), np.ravel(A_i), np.ravel(B_i), np.ravel(C_i), np.ravel(D_i), np.ravel(Dp_i), np.ravel(E_i),
+                            [float(tf_scale)]]).astype(np.float64)
+        if x.size != self.n_var:
+            raise ValueError(f"expected {self.n_var} parameters, got {x.size}")
+        return x
+
+    def _prep(self, x, y, t):
+        dev = torch.device("cuda", self.ctx.device)
+        xd = _dev_f64(x, dev)
+        if xd.dim() == 1:
+            xd = xd.unsqueeze(0)
+        if xd.shape[1] != self.n_var:
+            raise ValueError(f"x must be [B, {self.n_var}]")
+        B = xd.shape[0]
+        yd = _dev_f64(y, dev)
+        if yd.shape == (self.S,):
+            yb = 0
+        elif yd.shape == (B, self.S):
+            yb = 1
+        else:
+            raise ValueError(f"y must be [{self.S}] or [{B}, {self.S}]")
+        td = _dev_f64(np.atleast_1d(t) if not isinstance(t, torch.Tensor) else t, dev).reshape(-1)
+        if td.numel() not in (1, B):
+            raise ValueError("t must be a scalar or hold one value per candidate")
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        return dev, xd, yd, yb, td, int(td.numel() == B and B > 1), B
+
+    def rhs_batch(self, x, y, t, raw: bool = False) -> torch.Tensor:
+        """dy/dt [B, S] of B candidates: reference ``rhs_odeint(y, t, *args)`` (jacspeedup.py:392-394)."""
+        dev, xd, yd, yb, td, tb, B = self._prep(x, y, t)
+        out = torch.empty((B, self.S), dtype=torch.float64, device=dev)
+        self.ctx.check(self.ctx.lib.pk_network_rhs_batch(self.ctx.handle, self._h, B, _ptr(xd), int(raw), _ptr(yd), yb, _ptr(td), tb, _ptr(out)))
+        out._keepalive = (xd, yd, td)  # type: ignore[attr-defined]
+        return out
+
+    def jacobian_batch(self, x, y, t, raw: bool = False) -> torch.Tensor:
+        """Analytic Jacobian [B, S, S], row-major (the reference's Dfun is the finite-difference ``fd_jacobian_odeint``)."""
+        dev, xd, yd, yb, td, tb, B = self._prep(x, y, t)
+        out = torch.empty((B, self.S, self.S), dtype=torch.float64, device=dev)
+        self.ctx.check(self.ctx.lib.pk_network_jacobian_batch(self.ctx.handle, self._h, B, _ptr(xd), int(raw), _ptr(yd), yb, _ptr(td), tb, _ptr(out)))
+        out._keepalive = (xd, yd, td)  # type: ignore[attr-defined]
+        return out
+
+    def unpack_batch(self, x_raw) -> torch.Tensor:
+        """softplus of raw decision vectors (params.unpack_params, params.py:106-132) -> physical [B, n_var]."""
+        dev = torch.device("cuda", self.ctx.device)
+        xd = _dev_f64(x_raw, dev)
+        if xd.dim() == 1:
+            xd = xd.unsqueeze(0)
+        out = torch.empty_like(xd)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.check(self.ctx.lib.pk_network_unpack_batch(self.ctx.handle, self._h, xd.shape[0], _ptr(xd), _ptr(out)))
+        out._keepalive = (xd,)  # type: ignore[attr-defined]
+        return out
+
+    def default_y0(self) -> np.ndarray:
+        """``System.y0`` default (network.py:421-441): R = 1, P (state_0) = 1, phospho states 0.01."""
+        oy, ns = self._keep[0], self._keep[2]
+        y = np.zeros(self.S)
+        for i in range(self.N):
+            st = int(oy[i])
+            y[st] = 1.0; y[st + 1] = 1.0
+            cnt = ((1 << int(ns[i])) - 1) if self.model == 2 else int(ns[i])
+            y[st + 2: st + 2 + cnt] = 0.01
+        return y
