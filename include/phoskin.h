@@ -158,6 +158,12 @@ int pk_network_rhs_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_
  * (jacspeedup.py:398-588) as odeint's Dfun. */
 int pk_network_jacobian_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y, int y_is_batched,
                               const double* t, int t_is_batched, double* J);
+/* Replaces global_model.simulate.simulate_odeint(sys, t_eval, rtol, atol, mxstep) -> Y[T,S] (simulate.py:34-80) for B candidates
+ * of one network: x [B,n_var] and y0 ([S] or [B,S]) are device pointers, t is a HOST pointer to T strictly increasing times
+ * (t[0] = initial time), Y [B,T,S] device.  Integrator: ROS34PW2 Rosenbrock-W with the per-protein diagonal blocks of the analytic
+ * Jacobian; opts->rtol / atol / h0 / max_steps are honoured, method / linsolve are ignored.  Topologies 0, 1, 4. */
+int pk_network_simulate_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
+                              const double* t_host, int T, const pk_solver_opts* opts, double* Y, int32_t* status, int32_t* n_steps);
 /* global_model.params.unpack_params (softplus of the raw decision vectors): x_raw [B,n_var] -> x_phys [B,n_var]. */
 int pk_network_unpack_batch(pk_ctx*, pk_net*, int64_t B, const double* x_raw, double* x_phys);
 

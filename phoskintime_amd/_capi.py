@@ -55,7 +55,7 @@ SYMBOLS = (
     "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
     "pk_time_solve_protein_batch",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
-    "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch",
+    "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
 )
 
 _lib = None
@@ -100,6 +100,8 @@ def load():
     lib.pk_network_n_var.restype = i32; lib.pk_network_n_var.argtypes = [vp]
     for f in ("pk_network_rhs_batch", "pk_network_jacobian_batch"):
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, vp]
+    lib.pk_network_simulate_batch.restype = i32
+    lib.pk_network_simulate_batch.argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, optp, vp, vp, vp]
     lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
     lib.pk_time_solve_protein_batch.restype = dbl
     lib.pk_time_solve_protein_batch.argtypes = [vp, i32] + solve_args[1:]

@@ -5,6 +5,8 @@
 #include <vector>
 #include "../../include/phoskin.h"
 #include "pk_network.hpp"
+#include "pk_network_solve.hpp"
+#include <algorithm>
 
 struct pk_ctx;                                   // defined in pk_capi.hip
 extern "C" int pk_ctx_device(pk_ctx*);
@@ -80,6 +82,9 @@ struct pk_net {
   pk::NetDev d;
   std::vector<void*> allocs;
   size_t lds_bytes;
+  size_t solve_lds_bytes;
+  std::vector<double> kin_grid_host;
+  double* stops_dev = nullptr; int32_t* stop_out_dev = nullptr; size_t stops_cap = 0;
 };
 
 namespace {
@@ -136,6 +141,8 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
   v.tf_deg = upload(n, d->tf_deg, d->N, ok); v.driver_map = upload(n, d->driver_map, d->N, ok);
   v.kin_grid = upload(n, d->kin_grid, d->n_grid, ok); v.kin_Kmat = upload(n, d->kin_Kmat, (size_t)d->n_K * d->n_grid, ok);
   n->lds_bytes = ((size_t)v.n_var + v.S + v.n_K + v.sites + 3 * (size_t)v.N) * sizeof(double);
+  n->solve_lds_bytes = pk::net_solve_lds_doubles(v) * sizeof(double);
+  n->kin_grid_host.assign(d->kin_grid, d->kin_grid + d->n_grid);
   if (!ok || n->lds_bytes > 160 * 1024) {
     pk_ctx_fail(c, ok ? PK_ERR_UNSUPPORTED : PK_ERR_NOMEM, ok ? "network too large for one workgroup's LDS (160 KiB)" : "hipMalloc / hipMemcpy failed");
     pk_network_destroy(n);
@@ -145,12 +152,16 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
     (void)hipFuncSetAttribute((const void*)pk::net_rhs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->lds_bytes);
     (void)hipFuncSetAttribute((const void*)pk::net_jac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->lds_bytes);
   }
+  if (n->solve_lds_bytes > 48 * 1024 && n->solve_lds_bytes <= 160 * 1024)
+    (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
   return n;
 }
 
 void pk_network_destroy(pk_net* n) {
   if (!n) return;
   for (void* p : n->allocs) (void)hipFree(p);
+  if (n->stops_dev) (void)hipFree(n->stops_dev);
+  if (n->stop_out_dev) (void)hipFree(n->stop_out_dev);
   delete n;
 }
 
@@ -183,6 +194,65 @@ int pk_network_jacobian_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
   hipLaunchKernelGGL(pk::net_jac_kernel, dim3((unsigned)B), dim3(256), n->lds_bytes, (hipStream_t)pk_ctx_stream(c), n->d, x, x_is_raw, y,
                      y_is_batched, t, t_is_batched, J);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
+                              const double* t_host, int T, const pk_solver_opts* opts_in, double* Y, int32_t* status, int32_t* n_steps) {
+  if (!c || !n) return PK_ERR_ARG;
+  if (B < 0) return pk_ctx_fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (T < 1 || !t_host) return pk_ctx_fail(c, PK_ERR_ARG, "t must hold >= 1 time points (host pointer)");
+  if (B == 0) return PK_OK;
+  if (!x || !y0 || !Y) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
+  if (n->d.model == 2) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate: the combinatorial topology (model 2) is not integrated yet (rhs / Jacobian are available)");
+  if (n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
+  for (int k = 1; k < T; ++k) if (!(t_host[k] > t_host[k - 1])) return pk_ctx_fail(c, PK_ERR_ARG, "t must be strictly increasing");
+  pk_solver_opts o;
+  if (opts_in) o = *opts_in; else pk_default_opts(&o);
+  if (!(o.rtol > 0.0 && o.atol >= 0.0)) return pk_ctx_fail(c, PK_ERR_ARG, "rtol must be > 0 and atol >= 0");
+  if (o.max_steps <= 0) o.max_steps = 1000000;
+  // landing points: every output time after t[0] plus every bucket edge strictly inside (t[0], t[T-1])
+  std::vector<std::pair<double, int>> st;
+  for (int k = 1; k < T; ++k) st.push_back({t_host[k], k});
+  for (double gk : n->kin_grid_host) {
+    if (gk > t_host[0] && gk < t_host[T - 1]) {
+      bool dup = false;
+      for (int k = 1; k < T; ++k) if (t_host[k] == gk) { dup = true; break; }
+      if (!dup) st.push_back({gk, -1});
+    }
+  }
+  std::sort(st.begin(), st.end());
+  pk::NetSolveArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.x_is_raw = x_is_raw; a.y0 = y0; a.y0_batched = y0_is_batched ? 1 : 0; a.t0 = t_host[0]; a.T = T; a.Y = Y;
+  a.status = status; a.n_steps = n_steps; a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.max_steps = o.max_steps;
+  a.n_stops = (int)st.size();
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)pk_ctx_stream(c);
+  if (st.size() <= 64) {
+    for (size_t i = 0; i < st.size(); ++i) { a.stops_v[i] = st[i].first; a.stop_out_v[i] = st[i].second; }
+  } else {
+    // long output grids: stage through a per-network device buffer (the previous launch on it must have finished)
+    if (hipStreamSynchronize(stream) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipStreamSynchronize");
+    if (n->stops_cap < st.size()) {
+      if (n->stops_dev) (void)hipFree(n->stops_dev);
+      if (n->stop_out_dev) (void)hipFree(n->stop_out_dev);
+      n->stops_dev = nullptr; n->stop_out_dev = nullptr; n->stops_cap = 0;
+      if (hipMalloc((void**)&n->stops_dev, st.size() * 8) != hipSuccess || hipMalloc((void**)&n->stop_out_dev, st.size() * 4) != hipSuccess)
+        return pk_ctx_fail(c, PK_ERR_NOMEM, "hipMalloc");
+      n->stops_cap = st.size();
+    }
+    std::vector<double> sv(st.size()); std::vector<int32_t> so(st.size());
+    for (size_t i = 0; i < st.size(); ++i) { sv[i] = st[i].first; so[i] = st[i].second; }
+    if (hipMemcpy(n->stops_dev, sv.data(), sv.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(n->stop_out_dev, so.data(), so.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return pk_ctx_fail(c, PK_ERR_HIP, "hipMemcpy");
+    a.stops_p = n->stops_dev; a.stop_out_p = n->stop_out_dev;
+  }
+  const int threads = (n->d.S <= 64 && n->d.N <= 64 && n->d.n_var <= 256) ? 64 : 256;
+  hipLaunchKernelGGL(pk::net_solve_kernel, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
 }

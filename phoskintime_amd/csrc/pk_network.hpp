@@ -64,14 +64,14 @@ __device__ __forceinline__ double synth_rate(const double Ai, const double ts, c
 struct NetLds {
   double *p, *y, *Kt, *Sall, *Pvec, *synth, *dsyn;     // dsyn: d synth_i / d (TF . P_vec)_i   (Jacobian only)
   __device__ static size_t doubles(const NetDev& n) { return (size_t)n.n_var + n.S + n.n_K + n.sites + 3 * (size_t)n.N; }
+  __device__ NetLds() {}
   __device__ NetLds(double* base, const NetDev& n) {
     p = base; y = p + n.n_var; Kt = y + n.S; Sall = Kt + n.n_K; Pvec = Sall + n.sites; synth = Pvec + n.N; dsyn = synth + n.N;
   }
 };
 
-// Stages 1-4: everything the kinetic blocks need, for the candidate in L.p and the state in L.y.  All threads call.
-template <bool WITH_DERIV>
-__device__ __forceinline__ void net_prepare(const NetDev& n, const NetLds& L, const int jb) {
+// Stage 1-2 (depends on the candidate and the kinase bucket only): Kt and S_all.  All threads call; ends with a barrier.
+__device__ __forceinline__ void net_prepare_bucket(const NetDev& n, const NetLds& L, const int jb) {
   const NetSlices s(n.n_K, n.N, n.sites);
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int k = tid; k < n.n_K; k += nt) L.Kt[k] = n.kin_Kmat[(size_t)k * n.n_grid + jb] * L.p[s.ck + k];
@@ -81,6 +81,14 @@ __device__ __forceinline__ void net_prepare(const NetDev& n, const NetLds& L, co
     for (int q = n.W_indptr[r]; q < n.W_indptr[r + 1]; ++q) acc += n.W_data[q] * L.Kt[n.W_indices[q]];
     L.Sall[r] = acc;
   }
+  __syncthreads();
+}
+
+// Stage 3-4 (depends on the state in L.y): P_vec -> TF input -> synthesis rate (and its derivative).  Ends with a barrier.
+template <bool WITH_DERIV>
+__device__ __forceinline__ void net_prepare_state(const NetDev& n, const NetLds& L) {
+  const NetSlices s(n.n_K, n.N, n.sites);
+  const int tid = threadIdx.x, nt = blockDim.x;
   for (int i = tid; i < n.N; i += nt) {
     const int st = n.offset_y[i];
     double tot;
@@ -106,6 +114,12 @@ __device__ __forceinline__ void net_prepare(const NetDev& n, const NetLds& L, co
     if (WITH_DERIV) L.dsyn[i] = d * dv;
   }
   __syncthreads();
+}
+
+template <bool WITH_DERIV>
+__device__ __forceinline__ void net_prepare(const NetDev& n, const NetLds& L, const int jb) {
+  net_prepare_bucket(n, L, jb);
+  net_prepare_state<WITH_DERIV>(n, L);
 }
 
 // dy/dt of state `st_idx` (stage 5).  Reads only LDS.

@@ -126,6 +126,37 @@ class NetworkEngine:
         out._keepalive = (xd, yd, td)  # type: ignore[attr-defined]
         return out
 
+    def simulate_batch(self, x, t_eval, y0=None, raw: bool = False, rtol: float = 1e-7, atol: float = 1e-9, max_steps: int = 1000000,
+                       h0: float = 0.0):
+        """Y [B, T, S] for B candidates: reference ``simulate_odeint(sys, t_eval, rtol, atol, mxstep)`` (simulate.py:34-80) batched.
+        Returns (Y, status [B], n_steps [B, 2]) as GPU tensors; flagged candidates have NaN rows (callers test np.isfinite,
+        optproblem.py:125-133)."""
+        dev = torch.device("cuda", self.ctx.device)
+        xd = _dev_f64(x, dev)
+        if xd.dim() == 1:
+            xd = xd.unsqueeze(0)
+        if xd.shape[1] != self.n_var:
+            raise ValueError(f"x must be [B, {self.n_var}]")
+        B = xd.shape[0]
+        yd = _dev_f64(self.default_y0() if y0 is None else y0, dev)
+        if yd.shape == (self.S,):
+            yb = 0
+        elif yd.shape == (B, self.S):
+            yb = 1
+        else:
+            raise ValueError(f"y0 must be [{self.S}] or [{B}, {self.S}]")
+        th = np.ascontiguousarray(np.atleast_1d(np.asarray(t_eval, dtype=np.float64)))
+        T = th.size
+        Y = torch.empty((B, T, self.S), dtype=torch.float64, device=dev)
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        nsteps = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        opts = _capi.default_opts(rtol=rtol, atol=atol, max_steps=max_steps, h0=h0)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.check(self.ctx.lib.pk_network_simulate_batch(self.ctx.handle, self._h, B, _ptr(xd), int(raw), _ptr(yd), yb, th.ctypes.data, T,
+                                                             C.byref(opts), _ptr(Y), _ptr(status), _ptr(nsteps)))
+        Y._keepalive = (xd, yd)  # type: ignore[attr-defined]
+        return Y, status, nsteps
+
     def unpack_batch(self, x_raw) -> torch.Tensor:
         """softplus of raw decision vectors (params.unpack_params, params.py:106-132) -> physical [B, n_var]."""
         dev = torch.device("cuda", self.ctx.device)

@@ -89,3 +89,61 @@ def test_network_create_rejects_bad_topology():
     bad = dict(g); bad["offset_y"] = g["offset_y"].copy(); bad["offset_y"][1] += 1
     with pytest.raises(PhoskinError):
         NetworkEngine.from_npz(bad)
+
+
+@pytest.mark.parametrize("f", [x for x in GOLD if "_m2_" not in x.name], ids=lambda f: f.stem)
+def test_network_simulate_within_band_of_reference_lsoda(f):
+    """simulate_odeint batched (ROS34PW2, block-diagonal W) against the reference's LSODA run at 1e-12 (`Y_tight`); the reference's own
+    production tolerance (1e-8 / 1e-8, `Y_lsoda8`) is checked to be no closer to the truth than we are required to be."""
+    from phoskintime_amd.global_model import NetworkEngine
+    g = np.load(f)
+    eng = NetworkEngine.from_npz(g)
+    X = np.stack([_x(eng, g, k) for k in range(4)])
+    Y, st, ns = eng.simulate_batch(X, g["t_eval"])
+    Y = Y.cpu().numpy()
+    assert not st.cpu().numpy().any()
+    np.testing.assert_array_equal(Y[:, 0, :], np.broadcast_to(g["y0"], (4, eng.S)))
+    band = lambda a, b: float(np.max(np.abs(a - b) / (1e-8 + 1e-6 * np.abs(b))))
+    for k in range(2):
+        assert band(Y[k], g["Y_tight"][k]) <= 0.5, (f.name, k, band(Y[k], g["Y_tight"][k]))
+    for k in range(4):      # against the reference's own 1e-8 run: within its error + ours
+        assert band(Y[k], g["Y_lsoda8"][k]) <= 1.5
+    # determinism and independence of the batch composition
+    Y2, _, _ = eng.simulate_batch(X[[2, 0]], g["t_eval"])
+    np.testing.assert_array_equal(Y2.cpu().numpy(), Y[[2, 0]])
+    eng.close()
+
+
+def test_network_simulate_edge_cases():
+    from phoskintime_amd.global_model import NetworkEngine
+    from phoskintime_amd._capi import PhoskinError, ST_MAXSTEPS
+    g = np.load([x for x in GOLD if x.name == "network_m0_small.npz"][0])
+    eng = NetworkEngine.from_npz(g)
+    X = np.stack([_x(eng, g, k) for k in range(3)])
+    # output grid that does not contain the bucket edges: the integrator must still stop at every edge
+    t = np.array([0.0, 0.6, 3.0, 50.0, 960.0])
+    Y, st, ns = eng.simulate_batch(X, t)
+    Yfull, _, _ = eng.simulate_batch(X, g["t_eval"])
+    assert not st.cpu().numpy().any()
+    net = nm.Network.from_npz(g)
+    ref = nm.simulate_odeint(net, nm.Params.from_npz(g, 1), t, 1e-12, 1e-12, 500000)
+    assert np.max(np.abs(Y.cpu().numpy()[1] - ref) / (1e-8 + 1e-6 * np.abs(ref))) <= 0.5
+    np.testing.assert_allclose(Y.cpu().numpy()[:, -1], Yfull.cpu().numpy()[:, -1], rtol=1e-6, atol=1e-8)
+    # T = 1, step budget exhaustion, NaN candidate
+    Y1, st1, _ = eng.simulate_batch(X, [0.0])
+    assert Y1.shape == (3, 1, eng.S)
+    Ym, stm, _ = eng.simulate_batch(X, g["t_eval"], max_steps=10)
+    assert (stm.cpu().numpy() & ST_MAXSTEPS).all() and np.isnan(Ym.cpu().numpy()[:, -1]).all() and np.isfinite(Ym.cpu().numpy()[:, 0]).all()
+    Xb = X.copy(); Xb[1, 3] = np.nan
+    Yb, stb, _ = eng.simulate_batch(Xb, g["t_eval"])
+    stb = stb.cpu().numpy()
+    assert stb[1] != 0 and stb[0] == 0 and stb[2] == 0
+    np.testing.assert_array_equal(Yb.cpu().numpy()[[0, 2]], Yfull.cpu().numpy()[[0, 2]])
+    with pytest.raises(PhoskinError):
+        eng.simulate_batch(X, [0.0, 1.0, 1.0])
+    eng.close()
+    g2 = np.load([x for x in GOLD if x.name == "network_m2_small.npz"][0])
+    e2 = NetworkEngine.from_npz(g2)
+    with pytest.raises(PhoskinError):
+        e2.simulate_batch(np.ones((1, e2.n_var)), [0.0, 1.0])
+    e2.close()
