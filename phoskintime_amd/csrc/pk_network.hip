@@ -7,6 +7,7 @@
 #include "pk_network.hpp"
 #include "pk_network_solve.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 struct pk_ctx;                                   // defined in pk_capi.hip
 extern "C" int pk_ctx_device(pk_ctx*);
@@ -141,7 +142,7 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
   v.tf_deg = upload(n, d->tf_deg, d->N, ok); v.driver_map = upload(n, d->driver_map, d->N, ok);
   v.kin_grid = upload(n, d->kin_grid, d->n_grid, ok); v.kin_Kmat = upload(n, d->kin_Kmat, (size_t)d->n_K * d->n_grid, ok);
   n->lds_bytes = ((size_t)v.n_var + v.S + v.n_K + v.sites + 3 * (size_t)v.N) * sizeof(double);
-  n->solve_lds_bytes = pk::net_solve_lds_doubles(v) * sizeof(double);
+  n->solve_lds_bytes = pk::net_solve_lds_bytes(v, nnzT);
   n->kin_grid_host.assign(d->kin_grid, d->kin_grid + d->n_grid);
   if (!ok || n->lds_bytes > 160 * 1024) {
     pk_ctx_fail(c, ok ? PK_ERR_UNSUPPORTED : PK_ERR_NOMEM, ok ? "network too large for one workgroup's LDS (160 KiB)" : "hipMalloc / hipMemcpy failed");
@@ -152,8 +153,11 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
     (void)hipFuncSetAttribute((const void*)pk::net_rhs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->lds_bytes);
     (void)hipFuncSetAttribute((const void*)pk::net_jac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->lds_bytes);
   }
-  if (n->solve_lds_bytes > 48 * 1024 && n->solve_lds_bytes <= 160 * 1024)
-    (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
+  if (n->solve_lds_bytes > 48 * 1024 && n->solve_lds_bytes <= 160 * 1024) {
+    (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
+    (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
+    (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
+  }
   return n;
 }
 
@@ -208,6 +212,7 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
   if (n->d.model == 2) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate: the combinatorial topology (model 2) is not integrated yet (rhs / Jacobian are available)");
   if (n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
+  if (n->d.S > 1024 || n->d.N > 512) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate: S <= 1024 states and N <= 512 proteins per network");
   for (int k = 1; k < T; ++k) if (!(t_host[k] > t_host[k - 1])) return pk_ctx_fail(c, PK_ERR_ARG, "t must be strictly increasing");
   pk_solver_opts o;
   if (opts_in) o = *opts_in; else pk_default_opts(&o);
@@ -251,8 +256,12 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
       return pk_ctx_fail(c, PK_ERR_HIP, "hipMemcpy");
     a.stops_p = n->stops_dev; a.stop_out_p = n->stop_out_dev;
   }
-  const int threads = (n->d.S <= 64 && n->d.N <= 64 && n->d.n_var <= 256) ? 64 : 256;
-  hipLaunchKernelGGL(pk::net_solve_kernel, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+  // threads per candidate: every thread owns <= 4 states and <= 2 proteins (register-cached contexts in the kernel)
+  int threads = (n->d.S <= 128 && n->d.N <= 64) ? 64 : 256;        // measured at S = 500: 256 threads beat 128 by 1.33x
+  if (const char* e = getenv("PK_NET_THREADS")) { const int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && n->d.S <= 4 * v && n->d.N <= 2 * v) threads = v; }
+  if (n->d.model == 0)      hipLaunchKernelGGL(pk::net_solve_kernel<0>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+  else if (n->d.model == 1) hipLaunchKernelGGL(pk::net_solve_kernel<1>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+  else                      hipLaunchKernelGGL(pk::net_solve_kernel<4>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
 }

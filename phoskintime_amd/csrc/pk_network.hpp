@@ -123,17 +123,20 @@ __device__ __forceinline__ void net_prepare(const NetDev& n, const NetLds& L, co
 }
 
 // dy/dt of state `st_idx` (stage 5).  Reads only LDS.
-__device__ __forceinline__ double net_state_rhs(const NetDev& n, const NetLds& L, const int sidx) {
+// (i, loc, st, ss, ns) = protein, position inside its block, block start, site offset, site count of the state
+// MODEL >= 0 fixes the kinetic topology at compile time (the integrator kernels); -1 reads it from the network
+template <int MODEL = -1>
+__device__ __forceinline__ double net_state_rhs_ctx(const NetDev& n, const NetLds& L, const int i, const int loc, const int st,
+                                                    const int ss, const int ns) {
+  const int model = (MODEL >= 0) ? MODEL : n.model;
   const NetSlices s(n.n_K, n.N, n.sites);
-  const int i = n.state_prot[sidx], loc = n.state_local[sidx];
-  const int st = n.offset_y[i], ss = n.offset_s[i], ns = n.n_sites[i];
   const double* y = L.y + st;
   const double Bi = L.p[s.B + i], Ci = L.p[s.C + i], Di = L.p[s.D + i], Ei = L.p[s.E + i];
   const double* Dp = L.p + s.Dp + ss;
   const double* Sr = L.Sall + ss;
   const double R = y[0];
   if (loc == 0) return L.synth[i] - Bi * R;
-  if (n.model == 0) {
+  if (model == 0) {
     const double P = y[1];
     if (loc == 1) {
       if (ns == 0) return Ci * R - Di * P;
@@ -144,7 +147,7 @@ __device__ __forceinline__ double net_state_rhs(const NetDev& n, const NetLds& L
     const int j = loc - 2;
     return Sr[j] * P - (Ei + Dp[j] + Di) * y[loc];
   }
-  if (n.model == 4) {
+  if (model == 4) {
     const double P = y[1];
     if (loc == 1) {
       const double trans = (Ci * R) / (1.0 + R);
@@ -157,7 +160,7 @@ __device__ __forceinline__ double net_state_rhs(const NetDev& n, const NetLds& L
     const double fwd = (Sr[j] * P) / (1.0 + P);
     return fwd - (Dp[j] + Di) * y[loc] - Ei * y[loc];
   }
-  if (n.model == 1) {
+  if (model == 1) {
     const double P0 = y[1];
     if (loc == 1) {
       if (ns == 0) return Ci * R - Di * P0;
@@ -185,6 +188,11 @@ __device__ __forceinline__ double net_state_rhs(const NetDev& n, const NetLds& L
     }
   }
   return acc - loss * Pm;
+}
+
+__device__ __forceinline__ double net_state_rhs(const NetDev& n, const NetLds& L, const int sidx) {
+  const int i = n.state_prot[sidx];
+  return net_state_rhs_ctx(n, L, i, n.state_local[sidx], n.offset_y[i], n.offset_s[i], n.n_sites[i]);
 }
 
 // d f_row / d y_col  for row, col inside ONE protein block (the TF coupling is added separately)

@@ -29,6 +29,8 @@ constexpr double C21 = -4.5885607205580834861, C31 = -4.1847604823191607312, C32
 constexpr double C41 = -6.3681792001283577635, C42 = -6.7956209444668361844, C43 = 2.8700986043310560892;
 // y1 = Y4 + U4 (stiffly accurate: m = (A41, A42, A43, 1)); error estimate = sum E_i U_i
 constexpr double E1 = 0.27774994764796811038, E2 = -1.4032398951759990242, E3 = 1.7726301276675507452, E4 = 0.5;
+__device__ constexpr double TA[4][3] = {{0, 0, 0}, {A21, 0, 0}, {A31, A32, 0}, {A41, A42, A43}};
+__device__ constexpr double TC[4][3] = {{0, 0, 0}, {C21, 0, 0}, {C31, C32, 0}, {C41, C42, C43}};
 }  // namespace rosw
 
 struct NetSolveArgs {
@@ -56,8 +58,10 @@ __device__ __forceinline__ double block_max(double v, double* red) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const NetSolveArgs A) {
+template <int MODEL>
+__global__ __launch_bounds__(256, 3) void net_solve_kernel(const NetDev n, const NetSolveArgs A) {
   using namespace rosw;
+  constexpr int model = MODEL;
   extern __shared__ __align__(16) double lds[];
   NetLds L(lds, n);
   double* base = lds + NetLds::doubles(n);
@@ -70,13 +74,38 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
   double* sinv = winv + S;                // per protein: 1 / Schur pivot of the P row (arrow blocks)
   double* cR = sinv + N;                  // per protein: d f_P / d R
   double* gP = cR + N;                    // per protein: saturating-kinetics factor 1 / (1 + P)^2 (1 otherwise)
-  double* red = gP + N;                   // 17 doubles: reductions
+  double* red = gP + N;                   // 24 doubles: reductions
+  // static topology the inner loop touches, cached in LDS: TF CSR (data, degree, indptr, indices)
+  const int nnzT = n.TF_indptr[N];
+  double* tf_dat = red + 24;
+  double* tf_degl = tf_dat + nnzT;
+  int32_t* tf_ptr = reinterpret_cast<int32_t*>(tf_degl + N);
+  int32_t* tf_idx = tf_ptr + (N + 1);
   const NetSlices sl(n.n_K, N, n.sites);
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
   const double* stops = A.stops_p ? A.stops_p : A.stops_v;
   const int32_t* stop_out = A.stop_out_p ? A.stop_out_p : A.stop_out_v;
 
+  for (int k = tid; k < nnzT; k += nt) { tf_dat[k] = n.TF_data[k]; tf_idx[k] = n.TF_indices[k]; }
+  for (int k = tid; k <= N; k += nt) tf_ptr[k] = n.TF_indptr[k];
+  for (int k = tid; k < N; k += nt) tf_degl[k] = n.tf_deg[k];
+  // per-thread contexts in registers: up to KS states and KP proteins per thread (host guarantees S <= KS*nt, N <= KP*nt)
+  constexpr int KS = 4, KP = 2;
+  int s_i[KS], s_loc[KS], s_st[KS], s_ss[KS], s_ns[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int k = tid + q * nt;
+    if (k < S) { const int i = n.state_prot[k]; s_i[q] = i; s_loc[q] = n.state_local[k]; s_st[q] = n.offset_y[i]; s_ss[q] = n.offset_s[i]; s_ns[q] = n.n_sites[i]; }
+    else { s_i[q] = 0; s_loc[q] = 0; s_st[q] = 0; s_ss[q] = 0; s_ns[q] = 0; }
+  }
+  int p_st[KP], p_ss[KP], p_ns[KP], p_drv[KP];
+#pragma unroll
+  for (int q = 0; q < KP; ++q) {
+    const int i = tid + q * nt;
+    if (i < N) { p_st[q] = n.offset_y[i]; p_ss[q] = n.offset_s[i]; p_ns[q] = n.n_sites[i]; p_drv[q] = n.driver_map[i]; }
+    else { p_st[q] = 0; p_ss[q] = 0; p_ns[q] = 0; p_drv[q] = -1; }
+  }
   const double* xb = A.x + b * n.n_var;
   for (int k = tid; k < n.n_var; k += nt) L.p[k] = A.x_is_raw ? softplus(xb[k]) : xb[k];
   const double* y0 = A.y0 + (A.y0_batched ? b * S : 0);
@@ -86,13 +115,16 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
 
   // ---- block factorisation of  g I - J_blockdiag(y)  and block solve  x <- W^{-1} r  (in place: r -> x), one thread per protein
   auto factor = [&](const double g) {
-    for (int i = tid; i < N; i += nt) {
-      const int st = n.offset_y[i], ss = n.offset_s[i], ns = n.n_sites[i];
+#pragma unroll
+    for (int q_ = 0; q_ < KP; ++q_) {
+      const int i = tid + q_ * nt;
+      if (i >= N) break;
+      const int st = p_st[q_], ss = p_ss[q_], ns = p_ns[q_];
       const double Bi = L.p[sl.B + i], Ci = L.p[sl.C + i], Di = L.p[sl.D + i], Ei = L.p[sl.E + i];
       const double* Dp = L.p + sl.Dp + ss;
       const double* Sr = L.Sall + ss;
       winv[st] = 1.0 / (g + Bi);
-      if (n.model == 1) {
+      if (model == 1) {
         // tridiagonal over P0, P1..Pns: Thomas pivots
         cR[i] = Ci; gP[i] = 1.0;
         double d = g + Di + (ns ? Sr[0] : 0.0);
@@ -104,7 +136,7 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
           winv[st + 1 + q] = 1.0 / d;
         }
       } else {
-        const bool sat = n.model == 4;
+        const bool sat = model == 4;
         const double Rv = y[st], Pv = y[st + 1];
         const double g_p = sat ? 1.0 / ((1.0 + Pv) * (1.0 + Pv)) : 1.0;
         cR[i] = sat ? Ci / ((1.0 + Rv) * (1.0 + Rv)) : Ci;
@@ -122,13 +154,16 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
     __syncthreads();
   };
   auto block_solve = [&](const double* r, double* x) {
-    for (int i = tid; i < N; i += nt) {
-      const int st = n.offset_y[i], ss = n.offset_s[i], ns = n.n_sites[i];
+#pragma unroll
+    for (int q_ = 0; q_ < KP; ++q_) {
+      const int i = tid + q_ * nt;
+      if (i >= N) break;
+      const int st = p_st[q_], ss = p_ss[q_], ns = p_ns[q_];
       const double Ei = L.p[sl.E + i];
       const double* Sr = L.Sall + ss;
       const double xR = r[st] * winv[st];
       x[st] = xR;
-      if (n.model == 1) {
+      if (model == 1) {
         // Thomas: forward sweep (lower entries -k_{q-1}), back substitution (upper entries -E); x doubles as work space
         double prev = r[st + 1] + cR[i] * xR;
         x[st + 1] = prev;
@@ -147,21 +182,31 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
     }
     __syncthreads();
   };
-  // F(Ys) into R_ plus the c-combination, then solve into Uout.  L.y must point at the stage state.
-  auto stage = [&](double* Uout, const double hinv, const double c1, const double* u1, const double c2, const double* u2,
-                   const double c3, const double* u3) {
-    net_prepare_state<false>(n, L);
-    for (int k = tid; k < S; k += nt) {
-      double v = net_state_rhs(n, L, k);
-      if (u1) v = __builtin_fma(c1 * hinv, u1[k], v);
-      if (u2) v = __builtin_fma(c2 * hinv, u2[k], v);
-      if (u3) v = __builtin_fma(c3 * hinv, u3[k], v);
-      R_[k] = v;
+  // P_vec -> TF input -> synthesis rate for the state L.y points at (net_prepare_state with the LDS-cached topology)
+  auto prepare_state = [&]() {
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      const int i = tid + q * nt;
+      if (i >= N) break;
+      double tot;
+      if (p_drv[q] >= 0) tot = L.Kt[p_drv[q]];
+      else { tot = 0.0; for (int m_ = 0; m_ <= p_ns[q]; ++m_) tot += L.y[p_st[q] + 1 + m_]; }
+      L.Pvec[i] = tot;
     }
     __syncthreads();
-    block_solve(R_, Uout);
+    const double ts = L.p[sl.tf];
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      const int i = tid + q * nt;
+      if (i >= N) break;
+      double acc = 0.0;
+      for (int e_ = tf_ptr[i]; e_ < tf_ptr[i + 1]; ++e_) acc += tf_dat[e_] * L.Pvec[tf_idx[e_]];
+      double v = acc / tf_degl[i];
+      if (model != 4) v = v / (1.0 + fabs(v));
+      L.synth[i] = synth_rate(L.p[sl.A + i], ts, v, nullptr);
+    }
+    __syncthreads();
   };
-
   int status = PK_ST_OK, nacc = 0, nrej = 0;
   double tc = A.t0;
   int jb = net_bucket(tc, n.kin_grid, n.n_grid);
@@ -170,7 +215,7 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
   {
     // first step from the max-norm of y / sc and f / sc
     L.y = y;
-    net_prepare_state<false>(n, L);
+    prepare_state();
     double d0 = 0.0, d1 = 0.0;
     for (int k = tid; k < S; k += nt) {
       const double sc = A.atol + A.rtol * fabs(y[k]);
@@ -191,19 +236,31 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
       if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; break; }
       const double hinv = 1.0 / hs;
       factor(hinv * (1.0 / GAM));
-      // stage 1 at y
-      L.y = y;
-      stage(U1, hinv, 0.0, nullptr, 0.0, nullptr, 0.0, nullptr);
-      for (int k = tid; k < S; k += nt) Ys[k] = __builtin_fma(A21, U1[k], y[k]);
-      __syncthreads();
-      L.y = Ys;
-      stage(U2, hinv, C21, U1, 0.0, nullptr, 0.0, nullptr);
-      for (int k = tid; k < S; k += nt) Ys[k] = y[k] + (A31 * U1[k] + A32 * U2[k]);
-      __syncthreads();
-      stage(U3, hinv, C31, U1, C32, U2, 0.0, nullptr);
-      for (int k = tid; k < S; k += nt) Ys[k] = y[k] + (A41 * U1[k] + A42 * U2[k] + A43 * U3[k]);
-      __syncthreads();
-      stage(U4, hinv, C41, U1, C42, U2, C43, U3);
+      // four stages, one loop body (kept rolled: the body is large and register-hungry when replicated)
+      double* const Us[4] = {U1, U2, U3, U4};
+#pragma unroll 1
+      for (int sg = 0; sg < 4; ++sg) {
+        if (sg > 0) {
+          for (int k = tid; k < S; k += nt) {
+            double v = y[k];
+            for (int j = 0; j < sg; ++j) v = __builtin_fma(TA[sg][j], Us[j][k], v);
+            Ys[k] = v;
+          }
+          __syncthreads();
+        }
+        L.y = (sg == 0) ? y : Ys;
+        prepare_state();
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const int k = tid + q * nt;
+          if (k >= S) break;
+          double v = net_state_rhs_ctx<MODEL>(n, L, s_i[q], s_loc[q], s_st[q], s_ss[q], s_ns[q]);
+          for (int j = 0; j < sg; ++j) v = __builtin_fma(TC[sg][j] * hinv, Us[j][k], v);
+          R_[k] = v;
+        }
+        __syncthreads();
+        block_solve(R_, Us[sg]);
+      }
       // y1 = Ys + U4 ; err
       double e = 0.0;
       for (int k = tid; k < S; k += nt) {
@@ -265,6 +322,10 @@ __global__ __launch_bounds__(256) void net_solve_kernel(const NetDev n, const Ne
 
 __device__ __host__ inline size_t net_solve_lds_doubles(const NetDev& n) {
   return ((size_t)n.n_var + n.S + n.n_K + n.sites + 3 * (size_t)n.N) + 7 * (size_t)n.S + 3 * (size_t)n.N + 24;
+}
+// + the LDS copy of the TF CSR: nnz doubles + N doubles + (N + 1 + nnz) int32 (rounded up to doubles)
+__host__ inline size_t net_solve_lds_bytes(const NetDev& n, int nnzT) {
+  return (net_solve_lds_doubles(n) + (size_t)nnzT + n.N) * 8 + (((size_t)n.N + 1 + nnzT) * 4 + 7) / 8 * 8;
 }
 
 }  // namespace pk
