@@ -167,6 +167,26 @@ int pk_network_simulate_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int 
 /* global_model.params.unpack_params (softplus of the raw decision vectors): x_raw [B,n_var] -> x_phys [B,n_var]. */
 int pk_network_unpack_batch(pk_ctx*, pk_net*, int64_t B, const double* x_raw, double* x_phys);
 
+/* Fused objective of one optimiser candidate after the simulation -- replaces global_model.lossfn.LOSS_FN (lossfn.py:114-382; all eight
+ * LOSS_MODEs) and the assembly in GlobalODE_MOO._evaluate (optproblem.py:99-160).  pk_loss_data mirrors cache.prepare_fast_loss_data's
+ * arrays (HOST pointers, copied to HBM and index-checked by pk_network_loss_create for a time grid of T points).
+ *   Y [B,T,S] device; x [B,n_var] + defaults [n_var] (device; both optional: the prior penalty on A,B,C,D,E);
+ *   lambdas = {protein, rna, phospho, prior} (host); status [B] from the simulation (optional: flagged => fail_value);
+ *   loss_sums [B,3] raw weighted sums (LOSS_FN's return value) and / or F [B,3] the three objectives. */
+typedef struct pk_loss_data {
+  int32_t n_prot, n_rna, n_pho;
+  const int32_t *p_prot, *t_prot; const double *obs_prot, *w_prot;
+  const int32_t *p_rna, *t_rna;   const double *obs_rna, *w_rna;
+  const int32_t *p_pho, *s_pho, *t_pho; const double *obs_pho, *w_pho;
+  int32_t prot_base_idx, rna_base_idx, pho_base_idx;
+} pk_loss_data;
+typedef struct pk_loss pk_loss;
+pk_loss* pk_network_loss_create(pk_ctx*, pk_net*, const pk_loss_data*, int T);
+void     pk_network_loss_destroy(pk_loss*);
+int      pk_network_objective_batch(pk_ctx*, pk_net*, pk_loss*, int64_t B, const double* Y, int T, int loss_mode,
+                                    const double* x, int x_is_raw, const double* defaults, const double* lambdas, double fail_value,
+                                    const int32_t* status, double* loss_sums, double* F);
+
 /* Timing hook for bench.py: runs `iters` back-to-back launches of pk_solve_protein_batch on the context's
  * stream between two hipEvents and returns the mean kernel time per launch in milliseconds (< 0 on error). */
 double pk_time_solve_protein_batch(pk_ctx*, int iters, int model, int n_sites, int64_t B,

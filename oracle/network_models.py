@@ -258,3 +258,90 @@ def simulate_odeint(net: Network, p: Params, t_eval, rtol, atol, mxstep, y0=None
     f = lambda y, t: rhs(net, p, y, t)
     kw = dict(Dfun=(lambda y, t: fd_jacobian(net, p, y, t)), col_deriv=False) if use_fd_jac else {}
     return np.ascontiguousarray(odeint(f, y0, np.asarray(t_eval, float), rtol=rtol, atol=atol, mxstep=mxstep, **kw))
+
+
+# ------------------------------------------------------------------------------------------------ loss / objective
+EPS_LOSS = 1e-9   # lossfn.py:24
+
+
+def pointwise_loss(mode: int, diff: float, obs: float, pred: float) -> float:
+    """The LOSS_MODE switch of lossfn.py:149-165 with the eight robust losses of lossfn.py:28-110."""
+    if mode == 0:
+        return diff * diff
+    if mode == 1:
+        a = abs(diff); d = 0.5
+        return 0.5 * diff * diff if a <= d else d * (a - 0.5 * d)
+    if mode == 2:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            dl = float(np.log(diff + EPS_LOSS) - np.log(obs + EPS_LOSS))      # log of a possibly negative residual: NaN, as in the reference
+        x = dl / 0.5
+        return (0.5 * 0.5) * ((1.0 + x * x) ** 0.5 - 1.0)
+    if mode == 3:
+        s = abs(diff)
+        return s - 0.69314718056 if s > 20.0 else float(np.log(np.cosh(diff)))
+    if mode == 4:
+        return float(np.log(1.0 + (diff / 1.0) ** 2))
+    if mode == 5:
+        return (diff * diff) / (abs(pred) + 1e-6)
+    if mode == 6:
+        x2 = diff * diff
+        return x2 / (x2 + 1.0)
+    return (diff * diff + 1e-3 * 1e-3) ** 0.5 - 1e-3
+
+
+def loss_function(model: int, Y, ld: dict, mode: int):
+    """loss_function_noncomb (lossfn.py:114-246) / loss_function_comb (:250-382): three raw weighted sums."""
+    fc = lambda a, b: (a if a > EPS_LOSS else EPS_LOSS) / (b if b > EPS_LOSS else EPS_LOSS)
+    pm = ld["prot_map"]
+    lp = 0.0
+    for k in range(ld["p_prot"].size):
+        st, cnt = int(pm[ld["p_prot"][k], 0]), int(pm[ld["p_prot"][k], 1])
+        t = int(ld["t_prot"][k]); b = int(ld["prot_base_idx"])
+        if model == 2:
+            tt = 0.0; tb = 0.0
+            for m in range(cnt):
+                tt += Y[t, st + 1 + m]; tb += Y[b, st + 1 + m]
+        else:
+            tt = Y[t, st + 1]; tb = Y[b, st + 1]
+            for s in range(cnt):
+                tt += Y[t, st + 2 + s]; tb += Y[b, st + 2 + s]
+        pred = fc(tt, tb)
+        lp += ld["w_prot"][k] * pointwise_loss(mode, ld["obs_prot"][k] - pred, ld["obs_prot"][k], pred)
+    lr = 0.0
+    for k in range(ld["p_rna"].size):
+        st = int(pm[ld["p_rna"][k], 0])
+        pred = fc(Y[int(ld["t_rna"][k]), st], Y[int(ld["rna_base_idx"]), st])
+        lr += ld["w_rna"][k] * pointwise_loss(mode, ld["obs_rna"][k] - pred, ld["obs_rna"][k], pred)
+    lph = 0.0
+    for k in range(ld["p_pho"].size):
+        st, cnt = int(pm[ld["p_pho"][k], 0]), int(pm[ld["p_pho"][k], 1])
+        t = int(ld["t_pho"][k]); b = int(ld["pho_base_idx"]); j = int(ld["s_pho"][k])
+        if model == 2:
+            a = 0.0; c = 0.0
+            for m in range(cnt):
+                if m & (1 << j):
+                    a += Y[t, st + 1 + m]; c += Y[b, st + 1 + m]
+        else:
+            a = Y[t, st + 2 + j]; c = Y[b, st + 2 + j]
+        pred = fc(a, c)
+        lph += ld["w_pho"][k] * pointwise_loss(mode, ld["obs_pho"][k] - pred, ld["obs_pho"][k], pred)
+    return lp, lr, lph
+
+
+def objectives(net: Network, x_phys, defaults, Y, ld: dict, mode: int, lambdas: dict, fail_value: float = 1e12):
+    """GlobalODE_MOO._evaluate after the simulation (optproblem.py:99-160): prior penalty on A, B, C, D, E, finite check,
+    normalised weighted objectives."""
+    nK, N, sites = net.n_K, net.N, net.total_sites
+    sl = {"A_i": (nK, nK + N), "B_i": (nK + N, nK + 2 * N), "C_i": (nK + 2 * N, nK + 3 * N), "D_i": (nK + 3 * N, nK + 4 * N),
+          "E_i": (nK + 4 * N + sites, nK + 5 * N + sites)}
+    acc = 0.0; cnt = 0
+    for k, (a, b) in sl.items():
+        diff = (x_phys[a:b] - defaults[a:b]) / (defaults[a:b] + 1e-6)
+        acc += float(np.sum(diff ** 2)); cnt += diff.size
+    prior = lambdas["prior"] * (acc / max(1, cnt))
+    if Y is None or not np.all(np.isfinite(Y)):
+        return np.full(3, fail_value)
+    lp, lr, lph = loss_function(net.model, Y, ld, mode)
+    norm = lambda w: 1.0 / max(1e-6, float(np.sum(w)))
+    return np.array([lp * norm(ld["w_prot"]) * lambdas["protein"] + prior, lr * norm(ld["w_rna"]) * lambdas["rna"] + prior,
+                     lph * norm(ld["w_pho"]) * lambdas["phospho"] + prior])

@@ -40,6 +40,15 @@ class NetworkDesc(C.Structure):
                 ("tf_deg", C.c_void_p), ("driver_map", C.c_void_p), ("kin_grid", C.c_void_p), ("kin_Kmat", C.c_void_p)]
 
 
+class LossData(C.Structure):
+    """Mirror of ``pk_loss_data`` (include/phoskin.h)."""
+    _fields_ = [("n_prot", C.c_int32), ("n_rna", C.c_int32), ("n_pho", C.c_int32),
+                ("p_prot", C.c_void_p), ("t_prot", C.c_void_p), ("obs_prot", C.c_void_p), ("w_prot", C.c_void_p),
+                ("p_rna", C.c_void_p), ("t_rna", C.c_void_p), ("obs_rna", C.c_void_p), ("w_rna", C.c_void_p),
+                ("p_pho", C.c_void_p), ("s_pho", C.c_void_p), ("t_pho", C.c_void_p), ("obs_pho", C.c_void_p), ("w_pho", C.c_void_p),
+                ("prot_base_idx", C.c_int32), ("rna_base_idx", C.c_int32), ("pho_base_idx", C.c_int32)]
+
+
 class SolverOpts(C.Structure):
     """Mirror of ``pk_solver_opts`` (include/phoskin.h)."""
     _fields_ = [("method", C.c_int32), ("linsolve", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double),
@@ -56,6 +65,7 @@ SYMBOLS = (
     "pk_time_solve_protein_batch",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
+    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch",
 )
 
 _lib = None
@@ -102,6 +112,10 @@ def load():
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, vp]
     lib.pk_network_simulate_batch.restype = i32
     lib.pk_network_simulate_batch.argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, optp, vp, vp, vp]
+    lib.pk_network_loss_create.restype = vp; lib.pk_network_loss_create.argtypes = [vp, vp, C.POINTER(LossData), i32]
+    lib.pk_network_loss_destroy.restype = None; lib.pk_network_loss_destroy.argtypes = [vp]
+    lib.pk_network_objective_batch.restype = i32
+    lib.pk_network_objective_batch.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, i32, vp, vp, dbl, vp, vp, vp]
     lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
     lib.pk_time_solve_protein_batch.restype = dbl
     lib.pk_time_solve_protein_batch.argtypes = [vp, i32] + solve_args[1:]

@@ -169,6 +169,7 @@ void pk_network_destroy(pk_net* n) {
   delete n;
 }
 
+const pk::NetDev* pk_net_dev(const pk_net* n) { return &n->d; }
 int pk_network_n_states(const pk_net* n) { return n ? n->d.S : PK_ERR_ARG; }
 int pk_network_n_var(const pk_net* n) { return n ? n->d.n_var : PK_ERR_ARG; }
 

@@ -1,0 +1,210 @@
+// pk_network_loss.hip -- fused three-objective loss of the network path, one workgroup per candidate.
+//
+// Reference: global_model/lossfn.py:114-382 (loss_function_noncomb / _comb with the eight LOSS_MODE point losses, :28-110) and the
+// objective assembly of GlobalODE_MOO._evaluate (global_model/optproblem.py:99-160): prior penalty on A, B, C, D, E, finite check
+// of the trajectory (fail_value otherwise), sums normalised by the total weight of each modality, times the user lambdas.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
+#include "../../include/phoskin.h"
+#include "pk_network.hpp"
+
+struct pk_ctx;
+struct pk_net;
+extern "C" int pk_ctx_device(pk_ctx*);
+extern "C" void* pk_ctx_stream(pk_ctx*);
+extern "C" int pk_ctx_fail(pk_ctx*, int code, const char* msg);
+extern "C" const pk::NetDev* pk_net_dev(const pk_net*);
+
+namespace pk {
+
+struct LossDev {
+  int n_prot, n_rna, n_pho, base_prot, base_rna, base_pho;
+  const int32_t *p_prot, *t_prot, *p_rna, *t_rna, *p_pho, *s_pho, *t_pho;
+  const double *obs_prot, *w_prot, *obs_rna, *w_rna, *obs_pho, *w_pho;
+  double norm_p, norm_r, norm_ph;              // 1 / max(1e-6, sum w)   (optproblem.py:83-85)
+};
+
+__device__ __forceinline__ double point_loss(const int mode, double diff, const double obs, const double pred) {
+  constexpr double EPS = 1e-9;
+  switch (mode) {
+    case 0: return diff * diff;
+    case 1: { const double a = fabs(diff), d = 0.5; return a <= d ? 0.5 * diff * diff : d * (a - 0.5 * d); }
+    case 2: { diff = log(diff + EPS) - log(obs + EPS); const double x = diff / 0.5; return 0.25 * (sqrt(1.0 + x * x) - 1.0); }
+    case 3: { const double s = fabs(diff); return s > 20.0 ? s - 0.69314718056 : log(cosh(diff)); }
+    case 4: return log(1.0 + diff * diff);
+    case 5: return (diff * diff) / (fabs(pred) + 1e-6);
+    case 6: { const double x2 = diff * diff; return x2 / (x2 + 1.0); }
+    default: return sqrt(diff * diff + 1e-3 * 1e-3) - 1e-3;
+  }
+}
+
+__device__ __forceinline__ double fold_change(const double a, const double b) {
+  constexpr double EPS = 1e-9;
+  return (a > EPS ? a : EPS) / (b > EPS ? b : EPS);
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void net_objective_kernel(const NetDev n, const LossDev L, const double* __restrict__ Y, const int T,
+                                                            const int mode, const double* __restrict__ x, const int x_is_raw,
+                                                            const double* __restrict__ defaults, const double lam_p, const double lam_r,
+                                                            const double lam_ph, const double lam_prior, const double fail_value,
+                                                            const int32_t* __restrict__ status, double* __restrict__ sums, double* __restrict__ F) {
+  __shared__ double red[8];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x, S = n.S;
+  const double* Yb = Y + b * (size_t)T * S;
+  auto at = [&](int t, int s) { return Yb[(size_t)t * S + s]; };
+  const bool comb = n.model == 2;
+  double lp = 0.0, lr = 0.0, lph = 0.0;
+  for (int k = tid; k < L.n_prot; k += nt) {
+    const int i = L.p_prot[k], st = n.offset_y[i], t = L.t_prot[k];
+    const int cnt = comb ? (1 << n.n_sites[i]) : 1 + n.n_sites[i];
+    double tt = 0.0, tb = 0.0;
+    for (int m = 0; m < cnt; ++m) { tt += at(t, st + 1 + m); tb += at(L.base_prot, st + 1 + m); }
+    const double pred = fold_change(tt, tb);
+    lp += L.w_prot[k] * point_loss(mode, L.obs_prot[k] - pred, L.obs_prot[k], pred);
+  }
+  for (int k = tid; k < L.n_rna; k += nt) {
+    const int st = n.offset_y[L.p_rna[k]];
+    const double pred = fold_change(at(L.t_rna[k], st), at(L.base_rna, st));
+    lr += L.w_rna[k] * point_loss(mode, L.obs_rna[k] - pred, L.obs_rna[k], pred);
+  }
+  for (int k = tid; k < L.n_pho; k += nt) {
+    const int i = L.p_pho[k], st = n.offset_y[i], t = L.t_pho[k], j = L.s_pho[k];
+    double a, c;
+    if (comb) {
+      a = 0.0; c = 0.0;
+      const int cnt = 1 << n.n_sites[i];
+      for (int m = 0; m < cnt; ++m) if (m & (1 << j)) { a += at(t, st + 1 + m); c += at(L.base_pho, st + 1 + m); }
+    } else { a = at(t, st + 2 + j); c = at(L.base_pho, st + 2 + j); }
+    const double pred = fold_change(a, c);
+    lph += L.w_pho[k] * point_loss(mode, L.obs_pho[k] - pred, L.obs_pho[k], pred);
+  }
+  lp = block_sum(lp, red); lr = block_sum(lr, red); lph = block_sum(lph, red);
+  // np.all(np.isfinite(Y)) over the whole trajectory (optproblem.py:130)
+  double bad = 0.0;
+  for (size_t k = tid; k < (size_t)T * S; k += nt) { const double v = Yb[k]; if (v - v != 0.0) bad = 1.0; }
+  bad = block_sum(bad, red);
+  if (status && status[b] != 0) bad = 1.0;
+  double prior = 0.0;
+  if (x && defaults) {
+    const NetSlices sl(n.n_K, n.N, n.sites);
+    const double* xb = x + b * n.n_var;
+    double acc = 0.0;
+    for (int k = tid; k < 5 * n.N; k += nt) {
+      const int grp = k / n.N, i = k - grp * n.N;
+      const int off = (grp == 0 ? sl.A : grp == 1 ? sl.B : grp == 2 ? sl.C : grp == 3 ? sl.D : sl.E) + i;
+      const double p = x_is_raw ? softplus(xb[off]) : xb[off];
+      const double d = (p - defaults[off]) / (defaults[off] + 1e-6);
+      acc = __builtin_fma(d, d, acc);
+    }
+    acc = block_sum(acc, red);
+    prior = lam_prior * (acc / (double)(5 * n.N));
+  }
+  if (tid == 0) {
+    if (sums) { sums[3 * b] = lp; sums[3 * b + 1] = lr; sums[3 * b + 2] = lph; }
+    if (F) {
+      if (bad != 0.0) { F[3 * b] = fail_value; F[3 * b + 1] = fail_value; F[3 * b + 2] = fail_value; }
+      else {
+        F[3 * b] = (lp * L.norm_p) * lam_p + prior;
+        F[3 * b + 1] = (lr * L.norm_r) * lam_r + prior;
+        F[3 * b + 2] = (lph * L.norm_ph) * lam_ph + prior;
+      }
+    }
+  }
+}
+
+}  // namespace pk
+
+struct pk_loss {
+  pk::LossDev d;
+  std::vector<void*> allocs;
+  int T;
+};
+
+namespace {
+template <class T>
+const T* up(pk_loss* l, const T* host, size_t count, bool& ok) {
+  if (!ok) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, (count ? count : 1) * sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
+  l->allocs.push_back(p);
+  if (count && hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { ok = false; return nullptr; }
+  return (const T*)p;
+}
+double norm_of(const double* w, int n) { double s = 0.0; for (int i = 0; i < n; ++i) s += w[i]; return 1.0 / (s > 1e-6 ? s : 1e-6); }
+}  // namespace
+
+extern "C" {
+
+pk_loss* pk_network_loss_create(pk_ctx* c, pk_net* net, const pk_loss_data* d, int T) {
+  if (!c || !net || !d) return nullptr;
+  const pk::NetDev& n = *pk_net_dev(net);
+  if (T < 1 || d->n_prot < 0 || d->n_rna < 0 || d->n_pho < 0) { pk_ctx_fail(c, PK_ERR_ARG, "bad loss-data sizes"); return nullptr; }
+  auto bad_t = [&](int t) { return t < 0 || t >= T; };
+  if (bad_t(d->prot_base_idx) || bad_t(d->rna_base_idx) || bad_t(d->pho_base_idx)) { pk_ctx_fail(c, PK_ERR_ARG, "baseline index outside the time grid"); return nullptr; }
+  // index validation on the host (a bad index would be an out-of-bounds read on the GPU); n_sites is needed for s_pho
+  std::vector<int32_t> ns(n.N);
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess || hipMemcpy(ns.data(), n.n_sites, n.N * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+    pk_ctx_fail(c, PK_ERR_HIP, "hipMemcpy"); return nullptr;
+  }
+  for (int k = 0; k < d->n_prot; ++k) if (d->p_prot[k] < 0 || d->p_prot[k] >= n.N || bad_t(d->t_prot[k])) { pk_ctx_fail(c, PK_ERR_ARG, "protein observation index out of range"); return nullptr; }
+  for (int k = 0; k < d->n_rna; ++k) if (d->p_rna[k] < 0 || d->p_rna[k] >= n.N || bad_t(d->t_rna[k])) { pk_ctx_fail(c, PK_ERR_ARG, "rna observation index out of range"); return nullptr; }
+  for (int k = 0; k < d->n_pho; ++k) {
+    if (d->p_pho[k] < 0 || d->p_pho[k] >= n.N || bad_t(d->t_pho[k]) || d->s_pho[k] < 0 || d->s_pho[k] >= ns[d->p_pho[k]]) {
+      pk_ctx_fail(c, PK_ERR_ARG, "phospho observation index out of range"); return nullptr;
+    }
+  }
+  pk_loss* l = new pk_loss();
+  l->T = T;
+  bool ok = true;
+  pk::LossDev& v = l->d;
+  v.n_prot = d->n_prot; v.n_rna = d->n_rna; v.n_pho = d->n_pho;
+  v.base_prot = d->prot_base_idx; v.base_rna = d->rna_base_idx; v.base_pho = d->pho_base_idx;
+  v.p_prot = up(l, d->p_prot, d->n_prot, ok); v.t_prot = up(l, d->t_prot, d->n_prot, ok);
+  v.obs_prot = up(l, d->obs_prot, d->n_prot, ok); v.w_prot = up(l, d->w_prot, d->n_prot, ok);
+  v.p_rna = up(l, d->p_rna, d->n_rna, ok); v.t_rna = up(l, d->t_rna, d->n_rna, ok);
+  v.obs_rna = up(l, d->obs_rna, d->n_rna, ok); v.w_rna = up(l, d->w_rna, d->n_rna, ok);
+  v.p_pho = up(l, d->p_pho, d->n_pho, ok); v.s_pho = up(l, d->s_pho, d->n_pho, ok); v.t_pho = up(l, d->t_pho, d->n_pho, ok);
+  v.obs_pho = up(l, d->obs_pho, d->n_pho, ok); v.w_pho = up(l, d->w_pho, d->n_pho, ok);
+  v.norm_p = norm_of(d->w_prot, d->n_prot); v.norm_r = norm_of(d->w_rna, d->n_rna); v.norm_ph = norm_of(d->w_pho, d->n_pho);
+  if (!ok) { pk_ctx_fail(c, PK_ERR_NOMEM, "hipMalloc / hipMemcpy failed"); pk_network_loss_destroy(l); return nullptr; }
+  return l;
+}
+
+void pk_network_loss_destroy(pk_loss* l) {
+  if (!l) return;
+  for (void* p : l->allocs) (void)hipFree(p);
+  delete l;
+}
+
+int pk_network_objective_batch(pk_ctx* c, pk_net* net, pk_loss* l, int64_t B, const double* Y, int T, int loss_mode, const double* x,
+                               int x_is_raw, const double* defaults, const double* lambdas, double fail_value, const int32_t* status,
+                               double* loss_sums, double* F) {
+  if (!c || !net || !l) return PK_ERR_ARG;
+  if (B < 0) return pk_ctx_fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (T != l->T) return pk_ctx_fail(c, PK_ERR_ARG, "T differs from the grid the loss data were created for");
+  if (B == 0) return PK_OK;
+  if (!Y || (!loss_sums && !F)) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  if (F && !lambdas) return pk_ctx_fail(c, PK_ERR_ARG, "lambdas (protein, rna, phospho, prior) are required for F");
+  if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
+  const double lp = lambdas ? lambdas[0] : 1.0, lr = lambdas ? lambdas[1] : 1.0, lph = lambdas ? lambdas[2] : 1.0, lpr = lambdas ? lambdas[3] : 0.0;
+  hipLaunchKernelGGL(pk::net_objective_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)pk_ctx_stream(c), *pk_net_dev(net), l->d, Y, T,
+                     loss_mode, x, x_is_raw, defaults, lp, lr, lph, lpr, fail_value, status, loss_sums, F);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+}  // extern "C"

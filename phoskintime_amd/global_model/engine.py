@@ -157,6 +157,46 @@ class NetworkEngine:
         Y._keepalive = (xd, yd)  # type: ignore[attr-defined]
         return Y, status, nsteps
 
+    # ------------------------------------------------------------------ loss / objectives
+    def make_loss(self, loss_data: dict, T: int):
+        """Upload the arrays of ``cache.prepare_fast_loss_data`` (cache.py:19) for a solver grid of T points -> opaque handle."""
+        keep = {}
+        for k in ("p_prot", "t_prot", "p_rna", "t_rna", "p_pho", "s_pho", "t_pho"):
+            keep[k] = _i32(loss_data[k])
+        for k in ("obs_prot", "w_prot", "obs_rna", "w_rna", "obs_pho", "w_pho"):
+            keep[k] = _f64(loss_data[k])
+        d = _capi.LossData(keep["p_prot"].size, keep["p_rna"].size, keep["p_pho"].size,
+                           keep["p_prot"].ctypes.data, keep["t_prot"].ctypes.data, keep["obs_prot"].ctypes.data, keep["w_prot"].ctypes.data,
+                           keep["p_rna"].ctypes.data, keep["t_rna"].ctypes.data, keep["obs_rna"].ctypes.data, keep["w_rna"].ctypes.data,
+                           keep["p_pho"].ctypes.data, keep["s_pho"].ctypes.data, keep["t_pho"].ctypes.data, keep["obs_pho"].ctypes.data,
+                           keep["w_pho"].ctypes.data, int(loss_data["prot_base_idx"]), int(loss_data["rna_base_idx"]), int(loss_data["pho_base_idx"]))
+        h = self.ctx.lib.pk_network_loss_create(self.ctx.handle, self._h, C.byref(d), int(T))
+        if not h:
+            raise _capi.PhoskinError("pk_network_loss_create failed: " + (self.ctx.lib.pk_last_error(self.ctx.handle) or b"").decode())
+        return h
+
+    def free_loss(self, h):
+        self.ctx.lib.pk_network_loss_destroy(h)
+
+    def objective_batch(self, loss, Y: torch.Tensor, loss_mode: int = 0, x=None, raw: bool = False, defaults=None,
+                        lambdas=(1.0, 1.0, 1.0, 0.0), fail_value: float = 1e12, status: Optional[torch.Tensor] = None):
+        """(loss_sums [B, 3], F [B, 3]): LOSS_FN (lossfn.py:386) and the objectives of GlobalODE_MOO._evaluate (optproblem.py:137-160)."""
+        dev = torch.device("cuda", self.ctx.device)
+        Y = Y.contiguous()
+        B, T, S = Y.shape
+        if S != self.S:
+            raise ValueError("Y must be [B, T, S]")
+        xd = _dev_f64(x, dev) if x is not None else None
+        dd = _dev_f64(defaults, dev) if defaults is not None else None
+        sums = torch.empty((B, 3), dtype=torch.float64, device=dev)
+        F = torch.empty((B, 3), dtype=torch.float64, device=dev)
+        lam = (C.c_double * 4)(*[float(v) for v in lambdas])
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.check(self.ctx.lib.pk_network_objective_batch(self.ctx.handle, self._h, loss, B, _ptr(Y), T, int(loss_mode), _ptr(xd), int(raw),
+                                                              _ptr(dd), C.cast(lam, C.c_void_p), float(fail_value), _ptr(status), _ptr(sums), _ptr(F)))
+        sums._keepalive = (Y, xd, dd, status)  # type: ignore[attr-defined]
+        return sums, F
+
     def unpack_batch(self, x_raw) -> torch.Tensor:
         """softplus of raw decision vectors (params.unpack_params, params.py:106-132) -> physical [B, n_var]."""
         dev = torch.device("cuda", self.ctx.device)

@@ -147,3 +147,43 @@ def test_network_simulate_edge_cases():
     with pytest.raises(PhoskinError):
         e2.simulate_batch(np.ones((1, e2.n_var)), [0.0, 1.0])
     e2.close()
+
+
+@pytest.mark.parametrize("m", [0, 2])
+def test_network_loss_all_modes_match_reference(m):
+    """LOSS_FN on the GPU against the sums the reference's lossfn produced (all eight LOSS_MODEs; mode 2 is NaN in the reference, too)."""
+    import torch
+    from phoskintime_amd.global_model import NetworkEngine
+    gl = np.load(Path(__file__).resolve().parent / "golden" / f"network_loss_m{m}.npz")
+    g = np.load(Path(__file__).resolve().parent / "golden" / f"network_m{m}_small.npz")
+    eng = NetworkEngine.from_npz(g)
+    ld = {k: gl[k] for k in gl.files}
+    T = gl["Y"].shape[1]
+    loss = eng.make_loss(ld, T)
+    Y = torch.as_tensor(gl["Y"], device="cuda")
+    for mode in range(8):
+        sums, F = eng.objective_batch(loss, Y, loss_mode=mode, lambdas=(2.0, 3.0, 5.0, 0.0))
+        np.testing.assert_allclose(sums.cpu().numpy(), gl["loss_sums"][mode], rtol=1e-12, atol=0, equal_nan=True)
+        norm = [1.0 / max(1e-6, gl[w].sum()) for w in ("w_prot", "w_rna", "w_pho")]
+        want = gl["loss_sums"][mode] * np.array(norm) * np.array([2.0, 3.0, 5.0])
+        np.testing.assert_allclose(F.cpu().numpy(), want, rtol=1e-12, equal_nan=True)
+    # prior penalty + failure handling against the oracle's restatement of _evaluate
+    net = nm.Network.from_npz(g)
+    X = np.stack([_x(eng, g, k) for k in range(4)])
+    defaults = X[0] * 1.3
+    lam = dict(protein=1.0, rna=0.5, phospho=2.0, prior=0.7)
+    Yb = gl["Y"].copy(); Yb[2, 3, 1] = np.inf
+    st = torch.zeros(4, dtype=torch.int32, device="cuda"); st[3] = 2
+    sums, F = eng.objective_batch(loss, torch.as_tensor(Yb, device="cuda"), loss_mode=0, x=X, defaults=defaults,
+                                  lambdas=(lam["protein"], lam["rna"], lam["phospho"], lam["prior"]), status=st)
+    F = F.cpu().numpy()
+    for k in range(4):
+        want = nm.objectives(net, X[k], defaults, None if k == 3 else Yb[k], ld, 0, lam)
+        np.testing.assert_allclose(F[k], want, rtol=1e-12)
+    assert (F[2] == 1e12).all() and (F[3] == 1e12).all()
+    ld_bad = dict(ld); ld_bad["t_prot"] = ld["t_prot"].copy(); ld_bad["t_prot"][0] = T
+    from phoskintime_amd._capi import PhoskinError
+    with pytest.raises(PhoskinError):
+        eng.make_loss(ld_bad, T)
+    eng.free_loss(loss)
+    eng.close()

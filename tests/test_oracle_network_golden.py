@@ -49,3 +49,15 @@ def test_synthesis_rate_branches():
     u = 0.5 / 1.5
     assert nm.calculate_synthesis_rate(2.0, 3.0, 0.5) == 2.0 * (1.0 + (3.0 * u) / (1.0 + u + 1e-6))
     assert nm.calculate_synthesis_rate(2.0, 3.0, -0.5) == 2.0 / (1.0 + 3.0 * u)
+
+
+@pytest.mark.parametrize("m", [0, 2])
+def test_loss_function_matches_reference_all_modes(m):
+    """lossfn.loss_function_noncomb / _comb for every LOSS_MODE (reference outputs: tools/make_golden_loss.py)."""
+    g = np.load(Path(__file__).resolve().parent / "golden" / f"network_loss_m{m}.npz")
+    ld = {k: g[k] for k in g.files}
+    for mode in range(8):
+        for k in range(g["Y"].shape[0]):
+            got = np.array(nm.loss_function(m, g["Y"][k], ld, mode))
+            np.testing.assert_allclose(got, g["loss_sums"][mode, k], rtol=1e-13, atol=0, equal_nan=True)
+    assert np.isnan(g["loss_sums"][2]).any()      # LOSS_MODE 2 takes log(diff + eps) of negative residuals in the reference itself
