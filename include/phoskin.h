@@ -187,6 +187,10 @@ int      pk_network_objective_batch(pk_ctx*, pk_net*, pk_loss*, int64_t B, const
                                     const double* x, int x_is_raw, const double* defaults, const double* lambdas, double fail_value,
                                     const int32_t* status, double* loss_sums, double* F);
 
+/* Array form of the pred_fc columns of global_model.simulate.simulate_and_measure (simulate.py:119-202): fold changes for the index
+ * lists of a pk_loss (protein | rna | phospho, obs / w ignored), floor eps (the reference uses 1e-12 there): pred [B, n_prot+n_rna+n_pho]. */
+int pk_network_observables_batch(pk_ctx*, pk_net*, pk_loss*, int64_t B, const double* Y, int T, double eps, double* pred);
+
 /* Timing hook for bench.py: runs `iters` back-to-back launches of pk_solve_protein_batch on the context's
  * stream between two hipEvents and returns the mean kernel time per launch in milliseconds (< 0 on error). */
 double pk_time_solve_protein_batch(pk_ctx*, int iters, int model, int n_sites, int64_t B,

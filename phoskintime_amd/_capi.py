@@ -65,7 +65,7 @@ SYMBOLS = (
     "pk_time_solve_protein_batch",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
-    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch",
+    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_observables_batch",
 )
 
 _lib = None
@@ -116,6 +116,8 @@ def load():
     lib.pk_network_loss_destroy.restype = None; lib.pk_network_loss_destroy.argtypes = [vp]
     lib.pk_network_objective_batch.restype = i32
     lib.pk_network_objective_batch.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, i32, vp, vp, dbl, vp, vp, vp]
+    lib.pk_network_observables_batch.restype = i32
+    lib.pk_network_observables_batch.argtypes = [vp, vp, vp, i64, vp, i32, dbl, vp]
     lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
     lib.pk_time_solve_protein_batch.restype = dbl
     lib.pk_time_solve_protein_batch.argtypes = [vp, i32] + solve_args[1:]

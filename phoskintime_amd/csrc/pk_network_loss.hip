@@ -125,6 +125,40 @@ __global__ __launch_bounds__(256) void net_objective_kernel(const NetDev n, cons
   }
 }
 
+// pred[b, :] = fold-change observables for the index lists of L (protein | rna | phospho, in that order), floor `eps`:
+// the array form of simulate_and_measure's pred_fc columns (simulate.py:119-202, floor 1e-12) / of LOSS_FN's pred_fc (floor 1e-9).
+__global__ __launch_bounds__(256) void net_observables_kernel(const NetDev n, const LossDev L, const double* __restrict__ Y, const int T,
+                                                              const double eps, double* __restrict__ pred) {
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x, S = n.S;
+  const double* Yb = Y + b * (size_t)T * S;
+  auto at = [&](int t, int s) { return Yb[(size_t)t * S + s]; };
+  auto fc = [&](double a, double c) { return (a > eps ? a : eps) / (c > eps ? c : eps); };
+  const bool comb = n.model == 2;
+  double* out = pred + b * (size_t)(L.n_prot + L.n_rna + L.n_pho);
+  for (int k = tid; k < L.n_prot; k += nt) {
+    const int i = L.p_prot[k], st = n.offset_y[i], t = L.t_prot[k];
+    const int cnt = comb ? (1 << n.n_sites[i]) : 1 + n.n_sites[i];
+    double tt = 0.0, tb = 0.0;
+    for (int m = 0; m < cnt; ++m) { tt += at(t, st + 1 + m); tb += at(L.base_prot, st + 1 + m); }
+    out[k] = fc(tt, tb);
+  }
+  for (int k = tid; k < L.n_rna; k += nt) {
+    const int st = n.offset_y[L.p_rna[k]];
+    out[L.n_prot + k] = fc(at(L.t_rna[k], st), at(L.base_rna, st));
+  }
+  for (int k = tid; k < L.n_pho; k += nt) {
+    const int i = L.p_pho[k], st = n.offset_y[i], t = L.t_pho[k], j = L.s_pho[k];
+    double a, c;
+    if (comb) {
+      a = 0.0; c = 0.0;
+      const int cnt = 1 << n.n_sites[i];
+      for (int m = 0; m < cnt; ++m) if (m & (1 << j)) { a += at(t, st + 1 + m); c += at(L.base_pho, st + 1 + m); }
+    } else { a = at(t, st + 2 + j); c = at(L.base_pho, st + 2 + j); }
+    out[L.n_prot + L.n_rna + k] = fc(a, c);
+  }
+}
+
 }  // namespace pk
 
 struct pk_loss {
@@ -203,6 +237,19 @@ int pk_network_objective_batch(pk_ctx* c, pk_net* net, pk_loss* l, int64_t B, co
   const double lp = lambdas ? lambdas[0] : 1.0, lr = lambdas ? lambdas[1] : 1.0, lph = lambdas ? lambdas[2] : 1.0, lpr = lambdas ? lambdas[3] : 0.0;
   hipLaunchKernelGGL(pk::net_objective_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)pk_ctx_stream(c), *pk_net_dev(net), l->d, Y, T,
                      loss_mode, x, x_is_raw, defaults, lp, lr, lph, lpr, fail_value, status, loss_sums, F);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+int pk_network_observables_batch(pk_ctx* c, pk_net* net, pk_loss* l, int64_t B, const double* Y, int T, double eps, double* pred) {
+  if (!c || !net || !l) return PK_ERR_ARG;
+  if (B < 0) return pk_ctx_fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (T != l->T) return pk_ctx_fail(c, PK_ERR_ARG, "T differs from the grid the index lists were created for");
+  if (B == 0) return PK_OK;
+  if (!Y || !pred) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
+  hipLaunchKernelGGL(pk::net_observables_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)pk_ctx_stream(c), *pk_net_dev(net), l->d, Y, T, eps, pred);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
 }

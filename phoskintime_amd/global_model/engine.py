@@ -197,6 +197,40 @@ class NetworkEngine:
         sums._keepalive = (Y, xd, dd, status)  # type: ignore[attr-defined]
         return sums, F
 
+    def make_index_lists(self, times, t_prot, t_rna, t_pho):
+        """Index lists for EVERY protein / site at the requested times of each modality (what simulate_and_measure tabulates,
+        simulate.py:119-202) on the solver grid ``times`` -> (handle, layout dict); baselines: t = 0 (protein, phospho), t = 4 (RNA)."""
+        times = np.asarray(times, float)
+        bidx = lambda t0: int(np.argmin(np.abs(times - float(t0))))
+        sel = lambda tp: np.where(np.isin(times, np.asarray(tp, float)))[0].astype(np.int32)
+        ip, ir, iph = sel(t_prot), sel(t_rna), sel(t_pho)
+        ns = self._keep[2]
+        N = self.N
+        p_prot = np.repeat(np.arange(N, dtype=np.int32), ip.size); t_prot_i = np.tile(ip, N)
+        p_rna = np.repeat(np.arange(N, dtype=np.int32), ir.size); t_rna_i = np.tile(ir, N)
+        pp, ss = [], []
+        for i in range(N):
+            for j in range(int(ns[i])):
+                pp.append(i); ss.append(j)
+        pp = np.asarray(pp, np.int32); ss = np.asarray(ss, np.int32)
+        p_pho = np.repeat(pp, iph.size); s_pho = np.repeat(ss, iph.size); t_pho_i = np.tile(iph, pp.size)
+        one = lambda a: np.ones(a.size)
+        ld = dict(p_prot=p_prot, t_prot=t_prot_i, obs_prot=one(p_prot), w_prot=one(p_prot), p_rna=p_rna, t_rna=t_rna_i, obs_rna=one(p_rna),
+                  w_rna=one(p_rna), p_pho=p_pho, s_pho=s_pho, t_pho=t_pho_i, obs_pho=one(p_pho), w_pho=one(p_pho),
+                  prot_base_idx=bidx(0.0), rna_base_idx=bidx(4.0), pho_base_idx=bidx(0.0))
+        return self.make_loss(ld, times.size), ld
+
+    def observables_batch(self, lists, Y: torch.Tensor, n_obs: int, eps: float = 1e-12) -> torch.Tensor:
+        """pred_fc [B, n_obs] in (protein | rna | phospho) order for index lists made by ``make_index_lists`` / ``make_loss``."""
+        dev = torch.device("cuda", self.ctx.device)
+        Y = Y.contiguous()
+        B, T, _ = Y.shape
+        out = torch.empty((B, n_obs), dtype=torch.float64, device=dev)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.check(self.ctx.lib.pk_network_observables_batch(self.ctx.handle, self._h, lists, B, _ptr(Y), T, float(eps), _ptr(out)))
+        out._keepalive = (Y,)  # type: ignore[attr-defined]
+        return out
+
     def unpack_batch(self, x_raw) -> torch.Tensor:
         """softplus of raw decision vectors (params.unpack_params, params.py:106-132) -> physical [B, n_var]."""
         dev = torch.device("cuda", self.ctx.device)

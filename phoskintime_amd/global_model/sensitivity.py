@@ -1,0 +1,110 @@
+"""Network Morris screening (reference: global_model/sensitivity.py), batched and shardable.
+
+  compute_bounds / _reconstruct_params / _compute_scalar_metric     sensitivity.py:41-140  (host helpers, same semantics)
+  run_sensitivity_batch                                             the numerical core of run_sensitivity_analysis (:171-277): sample ->
+        candidates -> ONE simulate launch (rtol 1e-5 / atol 1e-7 as simulate_and_measure) -> fold-change observables -> scalar metric per
+        candidate -> (multi-GPU: one all-gather of Y) -> elementary-effects analysis.  The reference pickles the whole System per task."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from ..sensitivity import morris
+from ..distributed import shard_bounds, all_gather_replicas
+from .engine import NetworkEngine
+
+_ORDER = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i", "tf_scale")
+
+
+def compute_bounds(params_dict, perturbation=0.2):
+    bounds, names = [], []
+    for key, value in params_dict.items():
+        if isinstance(value, np.ndarray):
+            for i, v in enumerate(value):
+                lb, ub = v * (1 - perturbation), v * (1 + perturbation)
+                if abs(v) < 1e-6:
+                    lb, ub = 0.0, 0.01
+                bounds.append([max(0.0, lb), ub]); names.append(f"{key}_{i}")
+        else:
+            v = float(value)
+            lb, ub = v * (1 - perturbation), v * (1 + perturbation)
+            if abs(v) < 1e-6:
+                lb, ub = 0.0, 0.01
+            bounds.append([max(0.0, lb), ub]); names.append(key)
+    return {"num_vars": len(names), "names": names, "bounds": bounds}
+
+
+def _reconstruct_params(param_vector, names_map, original_shapes):
+    p_out, curr = {}, 0
+    for key, shape in original_shapes.items():
+        if shape == ():
+            p_out[key] = param_vector[curr]; curr += 1
+        else:
+            size = int(np.prod(shape))
+            p_out[key] = np.array(param_vector[curr: curr + size]); curr += size
+    return p_out
+
+
+def _compute_scalar_metric(df_prot, df_rna, df_phos, metric="total_signal"):
+    parts = [d["pred_fc"].values for d in (df_prot, df_rna, df_phos) if d is not None]
+    combined = np.concatenate(parts) if parts else np.array([])
+    if len(combined) == 0:
+        return 0.0
+    if metric == "mean":
+        return np.mean(combined)
+    if metric == "variance":
+        return np.var(combined)
+    if metric == "l2_norm":
+        return np.linalg.norm(combined)
+    return np.sum(combined)
+
+
+def scalar_metric_batch(pred: torch.Tensor, metric: str = "total_signal") -> torch.Tensor:
+    """_compute_scalar_metric over the rows of pred [B, n_obs] (GPU)."""
+    if metric == "mean":
+        return pred.mean(dim=1)
+    if metric == "variance":
+        return pred.var(dim=1, unbiased=False)
+    if metric == "l2_norm":
+        return torch.linalg.vector_norm(pred, dim=1)
+    return pred.sum(dim=1)
+
+
+def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, times_r, times_ph, perturbation: float = 0.05,
+                          trajectories: int = 100, num_levels: int = 40, metric: str = "total_signal", seed: Optional[int] = None,
+                          param_values: Optional[np.ndarray] = None, y0=None, conf_level: float = 0.95, rtol: float = 1e-5, atol: float = 1e-7):
+    """Returns dict(Si, problem, param_values, Y, status).  ``fitted_params`` maps the eight parameter groups (System.update order)
+    to arrays / a scalar; every entry is varied, as in the reference (sensitivity.py:196-215)."""
+    params = {k: (np.asarray(fitted_params[k], float) if k != "tf_scale" else float(fitted_params[k])) for k in _ORDER}
+    problem = compute_bounds(params, perturbation)
+    if param_values is None:
+        param_values = morris.sample(problem, N=trajectories, num_levels=num_levels, seed=seed)
+    X = np.ascontiguousarray(param_values, dtype=np.float64)            # flat vector order == candidate row order (both System.update order)
+    if X.shape[1] != eng.n_var:
+        raise ValueError(f"parameter vector has {X.shape[1]} entries, the network expects {eng.n_var}")
+    total = X.shape[0]
+    times = np.unique(np.concatenate([times_p, times_r, times_ph]).astype(np.float64))
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    lo, hi = shard_bounds(total, rank, world)
+    lists, ld = eng.make_index_lists(times, times_p, times_r, times_ph)
+    n_obs = ld["p_prot"].size + ld["p_rna"].size + ld["p_pho"].size
+    try:
+        if hi > lo:
+            Y, status, _ = eng.simulate_batch(X[lo:hi], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
+            pred = eng.observables_batch(lists, Y, n_obs, eps=1e-12)
+            yloc = scalar_metric_batch(pred, metric)
+            yloc = torch.where(status != 0, torch.zeros_like(yloc), yloc)          # failed simulations contribute Y = 0
+        else:
+            dev = torch.device("cuda", eng.ctx.device)
+            yloc = torch.empty(0, dtype=torch.float64, device=dev); status = torch.empty(0, dtype=torch.int32, device=dev)
+        Yall = all_gather_replicas(yloc, total) if world > 1 else yloc
+        stat = all_gather_replicas(status, total) if world > 1 else status
+        torch.cuda.current_stream().synchronize()
+    finally:
+        eng.free_loss(lists)
+    Yh = np.nan_to_num(Yall.cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0)
+    Si = morris.analyze(problem, X, Yh, num_levels=num_levels, conf_level=conf_level, seed=seed)
+    return {"Si": Si, "problem": problem, "param_values": X, "Y": Yh, "status": stat.cpu().numpy()}

@@ -1,0 +1,71 @@
+"""Drop-in names of the reference's ``global_model/simulate.py`` on the MI355X engine.
+
+``simulate_odeint(sys, t_eval, rtol, atol, mxstep)`` and ``simulate_and_measure(sys, idx, t_p, t_r, t_pho)`` accept the reference's
+``System`` / ``Index`` objects (duck-typed: only array attributes and ``idx.proteins`` / ``idx.sites`` are read) and see ``sys.update``
+mutations because parameters are packed from the object at call time.  The batched forms (``NetworkEngine.simulate_batch``,
+``measure_batch``) are what the optimiser / Morris drivers use."""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import config
+from .engine import NetworkEngine
+
+_engines: dict = {}
+
+
+def engine_for(sys, model=None) -> NetworkEngine:
+    """One ``NetworkEngine`` per reference ``System`` (the topology is static; parameters travel per call)."""
+    model = config.MODEL if model is None else model
+    key = (id(sys), model)
+    eng = _engines.get(key)
+    if eng is None:
+        eng = _engines[key] = NetworkEngine.from_system(sys, model)
+    return eng
+
+
+def candidate_of(sys, eng: NetworkEngine) -> np.ndarray:
+    return eng.pack_params(sys.c_k, sys.A_i, sys.B_i, sys.C_i, sys.D_i, sys.Dp_i, sys.E_i, sys.tf_scale)
+
+
+def simulate_odeint(sys, t_eval, rtol, atol, mxstep):
+    """Y [T, S] (C-contiguous float64) for the system's current parameters: reference simulate.py:34-80."""
+    eng = engine_for(sys)
+    y0 = np.asarray(sys.y0(), dtype=np.float64)
+    Y, status, _ = eng.simulate_batch(candidate_of(sys, eng)[None, :], np.asarray(t_eval, dtype=np.float64), y0=y0, rtol=rtol, atol=atol,
+                                      max_steps=max(int(mxstep), 1) * max(len(np.atleast_1d(t_eval)), 1))
+    return np.ascontiguousarray(Y[0].cpu().numpy())
+
+
+def measure_batch(eng: NetworkEngine, Y: torch.Tensor, times, t_points_p, t_points_r, t_points_pho):
+    """Fold-change observables of B trajectories: (pred [B, n_obs] GPU tensor, layout dict with the (protein, site, time) of each column)."""
+    lists, ld = eng.make_index_lists(times, t_points_p, t_points_r, t_points_pho)
+    n_obs = ld["p_prot"].size + ld["p_rna"].size + ld["p_pho"].size
+    try:
+        pred = eng.observables_batch(lists, Y, n_obs, eps=1e-12)
+        torch.cuda.current_stream().synchronize()
+    finally:
+        eng.free_loss(lists)
+    return pred, ld
+
+
+def simulate_and_measure(sys, idx, t_points_p, t_points_r, t_points_pho):
+    """(df_prot, df_rna, df_phos) with columns protein, [psite,] time, pred_fc: reference simulate.py:83-202 (one solve at
+    rtol 1e-5 / atol 1e-7 on the union grid, FC against t = 0 (protein, phospho) and t = 4 (RNA), rows filtered by exact time)."""
+    eng = engine_for(sys)
+    times = np.unique(np.concatenate([t_points_p, t_points_r, t_points_pho]).astype(np.float64))
+    y0 = np.asarray(sys.y0(), dtype=np.float64)
+    Y, _, _ = eng.simulate_batch(candidate_of(sys, eng)[None, :], times, y0=y0, rtol=1e-5, atol=1e-7, max_steps=5000 * times.size)
+    pred, ld = measure_batch(eng, Y, times, t_points_p, t_points_r, t_points_pho)
+    v = pred[0].cpu().numpy()
+    n_p, n_r = ld["p_prot"].size, ld["p_rna"].size
+    prots = np.asarray(idx.proteins, dtype=object)
+    df_p = pd.DataFrame({"protein": prots[ld["p_prot"]], "time": times[ld["t_prot"]], "pred_fc": v[:n_p]})
+    df_r = pd.DataFrame({"protein": prots[ld["p_rna"]], "time": times[ld["t_rna"]], "pred_fc": v[n_p:n_p + n_r]})
+    psite = np.asarray([idx.sites[i][j] for i, j in zip(ld["p_pho"], ld["s_pho"])], dtype=object)
+    df_pho = pd.DataFrame({"protein": prots[ld["p_pho"]], "psite": psite, "time": times[ld["t_pho"]], "pred_fc": v[n_p + n_r:]})
+    if df_pho.empty:
+        df_pho = pd.DataFrame(columns=["protein", "psite", "time", "pred_fc"])
+    return df_p, df_r, df_pho

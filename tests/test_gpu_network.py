@@ -187,3 +187,53 @@ def test_network_loss_all_modes_match_reference(m):
         eng.make_loss(ld_bad, T)
     eng.free_loss(loss)
     eng.close()
+
+
+def test_simulate_and_measure_and_network_morris():
+    """Array form of simulate_and_measure against a numpy restatement on the oracle trajectory; Morris driver end to end (small)."""
+    import torch
+    from phoskintime_amd.global_model import NetworkEngine
+    from phoskintime_amd.global_model.simulate import measure_batch
+    from phoskintime_amd.global_model.sensitivity import run_sensitivity_batch, compute_bounds, _reconstruct_params
+    g = np.load([x for x in GOLD if x.name == "network_m0_small.npz"][0])
+    eng = NetworkEngine.from_npz(g)
+    times = g["t_eval"]
+    tp = np.array([0.0, 0.5, 1.0, 4.0, 960.0]); tr = np.array([4.0, 15.0, 60.0]); tph = np.array([0.0, 2.0, 30.0])
+    Y = torch.as_tensor(g["Y_lsoda8"], device="cuda")
+    pred, ld = measure_batch(eng, Y, times, tp, tr, tph)
+    pred = pred.cpu().numpy()
+    # numpy restatement of simulate.py:119-202 for non-combinatorial layouts
+    for b in range(2):
+        Yb = g["Y_lsoda8"][b]; col = 0
+        want = []
+        for k in range(ld["p_prot"].size):
+            i, t = ld["p_prot"][k], ld["t_prot"][k]; st = g["offset_y"][i]; ns = g["n_sites"][i]
+            tot = Yb[:, st + 1] + Yb[:, st + 2:st + 2 + ns].sum(axis=1)
+            want.append(max(tot[t], 1e-12) / max(tot[0], 1e-12))
+        rb = int(np.argmin(np.abs(times - 4.0)))
+        for k in range(ld["p_rna"].size):
+            st = g["offset_y"][ld["p_rna"][k]]
+            want.append(max(Yb[ld["t_rna"][k], st], 1e-12) / max(Yb[rb, st], 1e-12))
+        for k in range(ld["p_pho"].size):
+            st = g["offset_y"][ld["p_pho"][k]] + 2 + ld["s_pho"][k]
+            want.append(max(Yb[ld["t_pho"][k], st], 1e-12) / max(Yb[0, st], 1e-12))
+        np.testing.assert_allclose(pred[b], np.array(want), rtol=1e-13)
+    assert ld["p_prot"].size == int(g["N"]) * tp.size and ld["p_pho"].size == int(g["total_sites"]) * tph.size
+    # Morris on the fitted point = parameter set 1
+    fitted = dict(c_k=g["c_k"][1], A_i=g["A_i"][1], B_i=g["B_i"][1], C_i=g["C_i"][1], D_i=g["D_i"][1], Dp_i=g["Dp_i"][1], E_i=g["E_i"][1],
+                  tf_scale=float(g["tf_scale"][1]))
+    out = run_sensitivity_batch(eng, fitted, tp, tr, tph, perturbation=0.05, trajectories=4, num_levels=8, seed=3)
+    D = eng.n_var
+    assert out["param_values"].shape == (4 * (D + 1), D) and out["Y"].shape == (4 * (D + 1),) and not out["status"].any()
+    assert len(out["Si"]["mu_star"]) == D and np.isfinite(out["Si"]["mu_star"]).all()
+    # one row re-done by hand: candidate -> simulate -> observables -> sum
+    row = out["param_values"][7]
+    Yr, _, _ = eng.simulate_batch(row[None], np.unique(np.concatenate([tp, tr, tph])), rtol=1e-5, atol=1e-7)
+    pr, _ = measure_batch(eng, Yr, np.unique(np.concatenate([tp, tr, tph])), tp, tr, tph)
+    assert out["Y"][7] == pytest.approx(float(pr.sum()), rel=1e-12)
+    prob = compute_bounds(fitted, 0.05)
+    assert prob["num_vars"] == D and prob["names"][0] == "c_k_0" and prob["names"][-1] == "tf_scale"
+    shapes = {k: (np.asarray(v).shape if k != "tf_scale" else ()) for k, v in fitted.items()}
+    rec = _reconstruct_params(row, None, shapes)
+    np.testing.assert_array_equal(eng.pack_params(**rec), row)
+    eng.close()
