@@ -1,7 +1,7 @@
 """Dev tool: time solve kernels for several (model, n_sites, B, method, linsolve) combos via pk_time_solve_protein_batch."""
 import sys, ctypes as C, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 from phoskintime_amd import batch, _capi
 
 def run(model, n, B, method, lin, lo=0.0, hi=20.0, rtol=1e-7, atol=1e-9, iters=3, rk4_h=None, seed=20260517):

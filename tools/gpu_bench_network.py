@@ -1,7 +1,7 @@
 """Dev tool: time pk_network_simulate_batch on the synthetic config-5-shaped network; compare a few candidates with the CPU oracle."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 from phoskintime_amd.global_model import NetworkEngine
 from phoskintime_amd.global_model import synthetic
 

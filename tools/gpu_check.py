@@ -1,7 +1,7 @@
 """Dev tool: run the HIP path against every golden file and print band errors (needs a GPU)."""
 import glob, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 from phoskintime_amd import batch
 from oracle import protein_models as pm
 
