@@ -6,6 +6,7 @@
 #include "../../include/phoskin.h"
 #include "pk_network.hpp"
 #include "pk_network_solve.hpp"
+#include "pk_network_solve_reg.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -84,6 +85,8 @@ struct pk_net {
   std::vector<void*> allocs;
   size_t lds_bytes;
   size_t solve_lds_bytes;
+  size_t solve_reg_lds_bytes;
+  int max_sites;
   std::vector<double> kin_grid_host;
   double* stops_dev = nullptr; int32_t* stop_out_dev = nullptr; size_t stops_cap = 0;
 };
@@ -143,6 +146,9 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
   v.kin_grid = upload(n, d->kin_grid, d->n_grid, ok); v.kin_Kmat = upload(n, d->kin_Kmat, (size_t)d->n_K * d->n_grid, ok);
   n->lds_bytes = ((size_t)v.n_var + v.S + v.n_K + v.sites + 3 * (size_t)v.N) * sizeof(double);
   n->solve_lds_bytes = pk::net_solve_lds_bytes(v, nnzT);
+  n->solve_reg_lds_bytes = pk::net_solve_reg_lds_bytes(v, nnzT);
+  n->max_sites = 0;
+  for (int i = 0; i < d->N; ++i) n->max_sites = std::max(n->max_sites, (int)d->n_sites[i]);
   n->kin_grid_host.assign(d->kin_grid, d->kin_grid + d->n_grid);
   if (!ok || n->lds_bytes > 160 * 1024) {
     pk_ctx_fail(c, ok ? PK_ERR_UNSUPPORTED : PK_ERR_NOMEM, ok ? "network too large for one workgroup's LDS (160 KiB)" : "hipMalloc / hipMemcpy failed");
@@ -257,12 +263,29 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
       return pk_ctx_fail(c, PK_ERR_HIP, "hipMemcpy");
     a.stops_p = n->stops_dev; a.stop_out_p = n->stop_out_dev;
   }
-  // threads per candidate: every thread owns <= 4 states and <= 2 proteins (register-cached contexts in the kernel)
-  int threads = (n->d.S <= 128 && n->d.N <= 64) ? 64 : 256;        // measured at S = 500: 256 threads beat 128 by 1.33x
-  if (const char* e = getenv("PK_NET_THREADS")) { const int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && n->d.S <= 4 * v && n->d.N <= 2 * v) threads = v; }
-  if (n->d.model == 0)      hipLaunchKernelGGL(pk::net_solve_kernel<0>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
-  else if (n->d.model == 1) hipLaunchKernelGGL(pk::net_solve_kernel<1>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
-  else                      hipLaunchKernelGGL(pk::net_solve_kernel<4>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+  // Register-resident kernel (one thread per protein) when every block fits its per-thread arrays; opts->linsolve ==
+  // PK_LINSOLVE_STRUCTURED forces the LDS kernel (kept as the general fallback and as the A/B reference).
+  const bool reg_ok = n->d.N <= 256 && n->max_sites <= 8 && n->solve_reg_lds_bytes <= 64 * 1024 && o.linsolve != PK_LINSOLVE_STRUCTURED;
+  if (reg_ok) {
+    const int threads = ((n->d.N + 63) / 64) * 64;
+    const size_t lb = n->solve_reg_lds_bytes;
+#define PK_REG_LAUNCH(M, MS) hipLaunchKernelGGL((pk::net_solve_reg_kernel<M, MS>), dim3((unsigned)B), dim3(threads), lb, stream, n->d, a)
+    if (n->max_sites <= 4) {
+      if (n->d.model == 0) PK_REG_LAUNCH(0, 4); else if (n->d.model == 1) PK_REG_LAUNCH(1, 4); else PK_REG_LAUNCH(4, 4);
+    } else if (n->max_sites <= 6) {
+      if (n->d.model == 0) PK_REG_LAUNCH(0, 6); else if (n->d.model == 1) PK_REG_LAUNCH(1, 6); else PK_REG_LAUNCH(4, 6);
+    } else {
+      if (n->d.model == 0) PK_REG_LAUNCH(0, 8); else if (n->d.model == 1) PK_REG_LAUNCH(1, 8); else PK_REG_LAUNCH(4, 8);
+    }
+#undef PK_REG_LAUNCH
+  } else {
+    // LDS kernel: every thread owns <= 4 states and <= 2 proteins (register-cached contexts in the kernel)
+    int threads = (n->d.S <= 128 && n->d.N <= 64) ? 64 : 256;        // measured at S = 500: 256 threads beat 128 by 1.33x
+    if (const char* e = getenv("PK_NET_THREADS")) { const int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && n->d.S <= 4 * v && n->d.N <= 2 * v) threads = v; }
+    if (n->d.model == 0)      hipLaunchKernelGGL(pk::net_solve_kernel<0>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+    else if (n->d.model == 1) hipLaunchKernelGGL(pk::net_solve_kernel<1>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+    else                      hipLaunchKernelGGL(pk::net_solve_kernel<4>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
 }

@@ -127,7 +127,7 @@ class NetworkEngine:
         return out
 
     def simulate_batch(self, x, t_eval, y0=None, raw: bool = False, rtol: float = 1e-7, atol: float = 1e-9, max_steps: int = 1000000,
-                       h0: float = 0.0):
+                       h0: float = 0.0, kernel: str = "auto"):
         """Y [B, T, S] for B candidates: reference ``simulate_odeint(sys, t_eval, rtol, atol, mxstep)`` (simulate.py:34-80) batched.
         Returns (Y, status [B], n_steps [B, 2]) as GPU tensors; flagged candidates have NaN rows (callers test np.isfinite,
         optproblem.py:125-133)."""
@@ -150,7 +150,8 @@ class NetworkEngine:
         Y = torch.empty((B, T, self.S), dtype=torch.float64, device=dev)
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
         nsteps = torch.zeros((B, 2), dtype=torch.int32, device=dev)
-        opts = _capi.default_opts(rtol=rtol, atol=atol, max_steps=max_steps, h0=h0)
+        # kernel = "auto": register-resident one-thread-per-protein kernel when eligible; "lds": the general LDS kernel
+        opts = _capi.default_opts(rtol=rtol, atol=atol, max_steps=max_steps, h0=h0, linsolve=("structured" if kernel == "lds" else "auto"))
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         self.ctx.check(self.ctx.lib.pk_network_simulate_batch(self.ctx.handle, self._h, B, _ptr(xd), int(raw), _ptr(yd), yb, th.ctypes.data, T,
                                                              C.byref(opts), _ptr(Y), _ptr(status), _ptr(nsteps)))

@@ -237,3 +237,21 @@ def test_simulate_and_measure_and_network_morris():
     rec = _reconstruct_params(row, None, shapes)
     np.testing.assert_array_equal(eng.pack_params(**rec), row)
     eng.close()
+
+
+@pytest.mark.parametrize("model", [0, 1, 4])
+def test_register_and_lds_network_kernels_agree(model):
+    """The one-thread-per-protein register kernel and the general LDS kernel implement the same method: on a config-5-shaped
+    synthetic network (S = 500, up to 6 sites per protein => MAXS = 8 path) they must agree far inside the parity band."""
+    from phoskintime_amd.global_model import NetworkEngine, synthetic
+    net = synthetic.make_network(model=model)
+    eng = NetworkEngine(**net)
+    X = synthetic.random_candidates(net, 24, seed=3)
+    t = np.unique(np.concatenate([net["kin_grid"], [15.0]]))
+    Ya, sa, na = eng.simulate_batch(X, t, kernel="auto")
+    Yb, sb, nb = eng.simulate_batch(X, t, kernel="lds")
+    assert not sa.cpu().numpy().any() and not sb.cpu().numpy().any()
+    Ya, Yb = Ya.cpu().numpy(), Yb.cpu().numpy()
+    assert np.max(np.abs(Ya - Yb) / (1e-8 + 1e-6 * np.abs(Yb))) <= 0.2
+    assert abs(int(na[:, 0].sum()) - int(nb[:, 0].sum())) <= 0.02 * int(nb[:, 0].sum())
+    eng.close()
