@@ -52,13 +52,16 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    # the collective path is also taken at world size 1 when launched under torch.distributed.run with PK_FORCE_COLLECTIVE=1
+    # (lets a 1-GPU box exercise exactly the code the 2/4/8-GPU runs execute)
+    use_dist = world > 1 or (os.environ.get("PK_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)
 
     from phoskintime_amd import batch, _capi
-    from phoskintime_amd.distributed import all_gather_replicas
 
     model, n_sites = _capi.DIST, 30
     S, P = batch.n_states(model, n_sites), batch.n_params(model, n_sites)
@@ -76,13 +79,22 @@ def main():
                             n_steps=torch.zeros((B, 2), dtype=torch.int32, device=dev))
     kw = dict(want_flat=False, metric="total_signal", method=args.method, linsolve=args.linsolve, rtol=args.rtol, atol=args.atol, out=out)
 
+    gathered_buf = torch.empty(B * world, dtype=torch.float64, device=dev) if use_dist else None
+
+    def gather():
+        """ONE collective per step: all-gather of the per-replica scalars (8 B / replica) over RCCL."""
+        if not use_dist:
+            return out.metric
+        dist.all_gather_into_tensor(gathered_buf, out.metric)
+        return gathered_buf
+
     def step():
         batch.solve_ode_batch(model, theta, y0, n_sites, tt, **kw)
-        return all_gather_replicas(out.metric, B * world) if world > 1 else out.metric
+        return gather()
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -96,10 +108,10 @@ def main():
         ev[i][0].record()
         batch.solve_ode_batch(model, theta, y0, n_sites, tt, **kw)
         ev[i][1].record()
-        gathered = all_gather_replicas(out.metric, B * world) if world > 1 else out.metric
+        gathered = gather()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -121,7 +133,7 @@ def main():
             "config": {"workload": "BASELINE config 3: 65536 replicas/GPU, models.distmod n_sites=30 (S=32, P=64), theta~U(0,20), "
                                    "y0=1, 14-point grid 0..960, adaptive %s rtol=%g atol=%g, linsolve=%s; outputs sol[B,14,32] + "
                                    "Morris total_signal[B]%s" % (args.method, args.rtol, args.atol, args.linsolve,
-                                                               "; 1 RCCL all-gather of Y per step" if world > 1 else ""),
+                                                               "; 1 RCCL all-gather of Y per step" if use_dist else ""),
                        "replicas_per_gpu": B, "n_states": S, "n_params": P, "n_timepoints": T, "method": args.method,
                        "parallelism": "replica-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -162,7 +174,7 @@ def main():
                                              "tolerances -> clip -> flat) on the oracle's numpy-vectorised distmod RHS, one process per core; "
                                              "wall %.1f s" % (nsamp, wall)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
