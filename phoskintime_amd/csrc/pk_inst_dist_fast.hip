@@ -18,7 +18,7 @@ void launch_dist_fast(const SolveArgs& a, int method, hipStream_t st) {
   if (n <= 4) launch_one<4, 1>(a, method, st);
   else if (n <= 8) launch_one<4, 2>(a, method, st);
   else if (n <= 16) launch_one<8, 2>(a, method, st);
-  else if (n <= 32) launch_one<8, 4>(a, method, st);
+  else if (n <= 32) launch_one<8, 4>(a, method, st);        // 4 lanes x 8 rows measured equal (65.9 vs 65.2 M/s) at half the occupancy
   else launch_one<16, 4>(a, method, st);
 }
 
