@@ -76,7 +76,8 @@ typedef struct pk_ctx pk_ctx;
 
 int         pk_version(void);
 /* One context per GPU / per thread.  Owns a HIP stream and a small workspace; nothing else. */
-pk_ctx*     pk_create(int device_id);
+pk_ctx*     pk_create(int device_id);          /* NULL on failure: reason in pk_create_error() */
+const char* pk_create_error(void);          /* thread-local; empty string after a successful pk_create */
 void        pk_destroy(pk_ctx*);
 const char* pk_last_error(pk_ctx*);            /* valid until the next call on this context */
 /* Launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's default

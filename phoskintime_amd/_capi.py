@@ -58,7 +58,7 @@ class SolverOpts(C.Structure):
 
 #: every symbol include/phoskin.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = (
-    "pk_version", "pk_create", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts",
+    "pk_version", "pk_create", "pk_create_error", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts",
     "pk_protein_n_states", "pk_protein_n_params", "pk_protein_flat_len",
     "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch",
     "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
@@ -76,6 +76,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # Load order matters: PyTorch-ROCm ships its own libamdhip64; if libphoskin_hip.so were dlopen'ed first it would bind the
+    # system HIP runtime and the process would end up with two runtimes (observed: pk_create fails after torch initialises).
+    # Importing torch first makes both use the one runtime torch has already loaded.
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise PhoskinLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -88,6 +92,7 @@ def load():
     optp = C.POINTER(SolverOpts)
     lib.pk_version.restype = i32
     lib.pk_create.restype = vp; lib.pk_create.argtypes = [i32]
+    lib.pk_create_error.restype = C.c_char_p; lib.pk_create_error.argtypes = []
     lib.pk_destroy.restype = None; lib.pk_destroy.argtypes = [vp]
     lib.pk_last_error.restype = C.c_char_p; lib.pk_last_error.argtypes = [vp]
     lib.pk_set_stream.restype = i32; lib.pk_set_stream.argtypes = [vp, vp]
@@ -149,7 +154,8 @@ class Context:
         self.device = int(device)
         self._h = self.lib.pk_create(self.device)
         if not self._h:
-            raise PhoskinError(f"pk_create({device}) failed: no usable HIP device (is a GPU visible?)")
+            why = self.lib.pk_create_error()
+            raise PhoskinError(f"pk_create({device}) failed: {why.decode() if why else 'no usable HIP device'}")
 
     def close(self):
         if getattr(self, "_h", None):

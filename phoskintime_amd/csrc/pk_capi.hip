@@ -79,15 +79,21 @@ int pk_protein_flat_len(int model, int n_sites, int T) {
   return (T > 5 ? T - 5 : 0) + T + n_sites * T;
 }
 
+static thread_local std::string g_create_err;
+const char* pk_create_error(void) { return g_create_err.c_str(); }
+
 pk_ctx* pk_create(int device_id) {
+  g_create_err.clear();
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return nullptr;
-  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess) { g_create_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return nullptr; }
+  if (ndev <= 0 || device_id < 0 || device_id >= ndev) { g_create_err = "device " + std::to_string(device_id) + " not in [0, " + std::to_string(ndev) + ")"; return nullptr; }
+  if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
   pk_ctx* c = new pk_ctx();
   c->device = device_id;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return nullptr; }
   c->stream = c->own_stream;
-  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_create_err = "hipEventCreate failed"; delete c; return nullptr; }
   return c;
 }
 
