@@ -114,6 +114,12 @@ int pk_rhs_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
 int pk_jacobian_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
                               const double* theta, double* J);
 
+/* Replaces config.config.score_fit(params, target, prediction, alpha, beta, gamma, delta, mu) (config/config.py:176-226) for B
+ * candidates: theta [B,P], target [N] (shared), pred [B,N] (e.g. the `flat` output) -> out [B].  weights = {alpha (rmse), beta (mae),
+ * gamma (var), delta (mse), mu (l2)} as a HOST pointer, NULL = all 1 (config/constants.py:77-83). */
+int pk_score_fit_batch(pk_ctx*, int64_t B, const double* theta, int P, const double* target, const double* pred, int N,
+                       const double* weights, double* out);
+
 /* Host-pointer conveniences (stage through HBM, synchronise before returning). */
 int pk_solve_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
                                 const double* theta, const double* y0, int y0_is_batched,

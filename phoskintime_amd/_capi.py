@@ -60,7 +60,7 @@ class SolverOpts(C.Structure):
 SYMBOLS = (
     "pk_version", "pk_create", "pk_create_error", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts",
     "pk_protein_n_states", "pk_protein_n_params", "pk_protein_flat_len",
-    "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch",
+    "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch", "pk_score_fit_batch",
     "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
     "pk_time_solve_protein_batch",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
@@ -124,6 +124,7 @@ def load():
     lib.pk_network_observables_batch.restype = i32
     lib.pk_network_observables_batch.argtypes = [vp, vp, vp, i64, vp, i32, dbl, vp]
     lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
+    lib.pk_score_fit_batch.restype = i32; lib.pk_score_fit_batch.argtypes = [vp, i64, vp, i32, vp, vp, i32, vp, vp]
     lib.pk_time_solve_protein_batch.restype = dbl
     lib.pk_time_solve_protein_batch.argtypes = [vp, i32] + solve_args[1:]
     _lib = lib

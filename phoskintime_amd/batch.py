@@ -168,3 +168,26 @@ def jacobian_batch(model, theta: ArrayLike, num_psites: int, device: Optional[in
         ctx.check(ctx.lib.pk_jacobian_protein_batch(ctx.handle, mid, n, th.shape[0], _ptr(th), _ptr(out)))
         out._keepalive = (th,)  # type: ignore[attr-defined]
     return out
+
+
+def score_fit_batch(theta: ArrayLike, target: ArrayLike, prediction: ArrayLike, alpha: float = 1.0, beta: float = 1.0, gamma: float = 1.0,
+                    delta: float = 1.0, mu: float = 1.0, device: Optional[int] = None) -> torch.Tensor:
+    """``config.config.score_fit`` (reference config/config.py:176-226) for B candidates: theta [B, P], target [N], prediction [B, N]."""
+    ctx = get_context(device)
+    dev = torch.device("cuda", ctx.device)
+    th = _dev_f64(theta, dev); pr = _dev_f64(prediction, dev); tg = _dev_f64(target, dev).reshape(-1)
+    if th.dim() == 1:
+        th = th.unsqueeze(0)
+    if pr.dim() == 1:
+        pr = pr.unsqueeze(0)
+    B, P = th.shape
+    N = tg.numel()
+    if pr.shape != (B, N):
+        raise ValueError(f"prediction must be [{B}, {N}]")
+    out = torch.empty((B,), dtype=torch.float64, device=dev)
+    w = (C.c_double * 5)(alpha, beta, gamma, delta, mu)
+    if B:
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ctx.check(ctx.lib.pk_score_fit_batch(ctx.handle, B, _ptr(th), P, _ptr(tg), _ptr(pr), N, C.cast(w, C.c_void_p), _ptr(out)))
+        out._keepalive = (th, pr, tg)  # type: ignore[attr-defined]
+    return out

@@ -314,3 +314,44 @@ double pk_time_solve_protein_batch(pk_ctx* c, int iters, int model, int n_sites,
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ score_fit (a6)
+namespace pk {
+// One wave per candidate: residual r = |target - pred| / N ;  score = delta sum r^2 + alpha sqrt(mean r^2) + beta mean r
+//   + gamma var(r) + mu ||theta||_2 / len(theta)            (config/config.py:176-226)
+__global__ __launch_bounds__(256) void score_fit_kernel(const double* __restrict__ theta, const int P, const double* __restrict__ target,
+                                                        const double* __restrict__ pred, const int N, const long long B,
+                                                        const double alpha, const double beta, const double gamma, const double delta,
+                                                        const double mu, double* __restrict__ out) {
+  const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const double* pb = pred + b * N;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < N; k += 64) { const double r = fabs(target[k] - pb[k]) / (double)N; s1 += r; s2 = __builtin_fma(r, r, s2); }
+  double t2 = 0.0;
+  const double* tb = theta + b * P;
+  for (int k = lane; k < P; k += 64) t2 = __builtin_fma(tb[k], tb[k], t2);
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); t2 += __shfl_xor(t2, off); }
+  const double mean = s1 / N;
+  // two-pass variance like np.var
+  double v = 0.0;
+  for (int k = lane; k < N; k += 64) { const double d = fabs(target[k] - pb[k]) / (double)N - mean; v = __builtin_fma(d, d, v); }
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if (lane == 0) out[b] = delta * s2 + alpha * sqrt(s2 / N) + beta * mean + gamma * (v / N) + mu * (sqrt(t2) / P);
+}
+}  // namespace pk
+
+extern "C" int pk_score_fit_batch(pk_ctx* c, int64_t B, const double* theta, int P, const double* target, const double* pred, int N,
+                                  const double* weights, double* out) {
+  if (!c) return PK_ERR_ARG;
+  if (B < 0 || P < 1 || N < 1) return fail(c, PK_ERR_ARG, "B >= 0, P >= 1, N >= 1 required");
+  if (B == 0) return PK_OK;
+  if (!theta || !target || !pred || !out) return fail(c, PK_ERR_ARG, "null pointer");
+  const double a = weights ? weights[0] : 1.0, b = weights ? weights[1] : 1.0, g = weights ? weights[2] : 1.0, d = weights ? weights[3] : 1.0,
+               m = weights ? weights[4] : 1.0;
+  PK_HIP(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(pk::score_fit_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, c->stream, theta, P, target, pred, N, (long long)B, a, b, g, d, m, out);
+  PK_HIP(c, hipGetLastError());
+  return PK_OK;
+}

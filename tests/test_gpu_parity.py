@@ -326,3 +326,19 @@ def test_morris_driver_and_knockouts_batched(eng, golden_files):
     th = popt.copy(); th[0] = 0; th[2] = 0; th[4:4 + n] = 0
     assert pm.band_error(sol[k], np.clip(pm.solve_exact_lti(model, th, y0, n, g["t"]), 0, None)) <= 0.1
     np.testing.assert_array_equal(sol[0], _np(eng.solve_ode_batch(model, popt[None], y0, n, g["t"]).sol)[0])     # no knock-out
+
+
+def test_score_fit_batch_matches_reference(eng, golden_files):
+    """config.config.score_fit on the GPU against the values the reference's own function produced (stored in the fixtures)."""
+    for f in golden_files[::4]:
+        g, model, n = _load(f)
+        th = g["theta"]
+        pred = g["flat_default"]
+        tgt = g["score_target0"]
+        got = eng.score_fit_batch(th, tgt, pred).cpu().numpy()
+        want = np.array([pm.score_fit(th[k], tgt, pred[k]) for k in range(th.shape[0])])
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+        assert got[0] == pytest.approx(float(g["score_fit"][0]), rel=1e-12)
+        w = eng.score_fit_batch(th, tgt, pred, alpha=0.5, beta=2.0, gamma=0.0, delta=3.0, mu=0.1).cpu().numpy()
+        want = np.array([pm.score_fit(th[k], tgt, pred[k], alpha=0.5, beta=2.0, gamma=0.0, delta=3.0, mu=0.1) for k in range(th.shape[0])])
+        np.testing.assert_allclose(w, want, rtol=1e-12)
