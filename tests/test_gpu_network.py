@@ -255,3 +255,62 @@ def test_register_and_lds_network_kernels_agree(model):
     assert np.max(np.abs(Ya - Yb) / (1e-8 + 1e-6 * np.abs(Yb))) <= 0.2
     assert abs(int(na[:, 0].sum()) - int(nb[:, 0].sum())) <= 0.02 * int(nb[:, 0].sum())
     eng.close()
+
+
+def _fake_system(g, k):
+    """A stand-in with the attribute surface of the reference's System / Index (network.py:28-526) built from a golden file."""
+    from types import SimpleNamespace
+    N = int(g["N"]); nK = int(g["n_K"])
+    prots = [f"P{i:03d}" for i in range(N)]
+    kin = [f"K{j:02d}" for j in range(nK)]
+    # driver_map -> names: protein i driven by kinase d is "the kinase itself"; keep it simple: map through p2i / k2i
+    p2i = {p: i for i, p in enumerate(prots)}
+    k2i = {}
+    kinases = []
+    drv = g["driver_map"]
+    used = {}
+    for i in range(N):
+        if drv[i] >= 0 and int(drv[i]) not in used:
+            used[int(drv[i])] = prots[i]
+    for j in range(nK):
+        name = used.get(j, kin[j])
+        kinases.append(name); k2i[name] = j
+    proxy = {}
+    for i in range(N):        # a second protein driven by an already-used kinase is an orphan proxied to it
+        if drv[i] >= 0 and used[int(drv[i])] != prots[i]:
+            proxy[prots[i]] = used[int(drv[i])]
+    sites = [[f"S{10 * (j + 1)}" for j in range(int(ns))] for ns in g["n_sites"]]
+    idx = SimpleNamespace(N=N, proteins=prots, kinases=kinases, p2i=p2i, k2i=k2i, proxy_map=proxy, sites=sites,
+                          offset_y=g["offset_y"], offset_s=g["offset_s"], n_sites=g["n_sites"])
+    sysm = SimpleNamespace(idx=idx, W_indptr=g["W_indptr"], W_indices=g["W_indices"], W_data=g["W_data"], TF_indptr=g["TF_indptr"],
+                           TF_indices=g["TF_indices"], TF_data=g["TF_data"], tf_deg=g["tf_deg"], kin_grid=g["kin_grid"], kin_Kmat=g["kin_Kmat"],
+                           c_k=g["c_k"][k].copy(), A_i=g["A_i"][k].copy(), B_i=g["B_i"][k].copy(), C_i=g["C_i"][k].copy(), D_i=g["D_i"][k].copy(),
+                           Dp_i=g["Dp_i"][k].copy(), E_i=g["E_i"][k].copy(), tf_scale=float(g["tf_scale"][k]), y0=lambda: g["y0"].copy())
+    return sysm, idx
+
+
+def test_dropin_simulate_odeint_and_measure_with_system_object():
+    """global_model.simulate.simulate_odeint / simulate_and_measure take the reference's System / Index objects and see update()s."""
+    from phoskintime_amd.global_model import simulate as gsim
+    from phoskintime_amd.global_model import config as gcfg
+    g = np.load([x for x in GOLD if x.name == "network_m0_small.npz"][0])
+    gcfg.MODEL = 0
+    sysm, idx = _fake_system(g, 1)
+    eng = gsim.engine_for(sysm)
+    np.testing.assert_array_equal(eng._keep[10], g["driver_map"])              # driver_map rebuilt exactly as network.py:454-469 does
+    Y = gsim.simulate_odeint(sysm, g["t_eval"], 1e-8, 1e-8, 200000)
+    assert Y.shape == g["Y_lsoda8"][1].shape and Y.flags["C_CONTIGUOUS"]
+    assert np.max(np.abs(Y - g["Y_tight"][1]) / (1e-8 + 1e-6 * np.abs(g["Y_tight"][1]))) <= 0.5
+    # mutate parameters like System.update does: the next call must see them
+    sysm.A_i[:] = g["A_i"][0]; sysm.B_i[:] = g["B_i"][0]; sysm.C_i[:] = g["C_i"][0]; sysm.D_i[:] = g["D_i"][0]; sysm.Dp_i[:] = g["Dp_i"][0]
+    sysm.E_i[:] = g["E_i"][0]; sysm.c_k[:] = g["c_k"][0]; sysm.tf_scale = float(g["tf_scale"][0])
+    Y0 = gsim.simulate_odeint(sysm, g["t_eval"], 1e-8, 1e-8, 200000)
+    assert np.max(np.abs(Y0 - g["Y_tight"][0]) / (1e-8 + 1e-6 * np.abs(g["Y_tight"][0]))) <= 0.5
+    tp = np.array([0.0, 1.0, 960.0]); tr = np.array([4.0, 60.0]); tph = np.array([0.0, 30.0])
+    dfp, dfr, dfph = gsim.simulate_and_measure(sysm, idx, tp, tr, tph)
+    assert list(dfp.columns) == ["protein", "time", "pred_fc"] and list(dfph.columns) == ["protein", "psite", "time", "pred_fc"]
+    assert len(dfp) == idx.N * 3 and len(dfr) == idx.N * 2 and len(dfph) == int(g["total_sites"]) * 2
+    assert set(dfp["time"]) == set(tp) and set(dfr["time"]) == set(tr)
+    assert np.allclose(dfp[dfp["time"] == 0.0]["pred_fc"], 1.0) and np.allclose(dfr[dfr["time"] == 4.0]["pred_fc"], 1.0)
+    from phoskintime_amd.global_model.sensitivity import _compute_scalar_metric
+    assert _compute_scalar_metric(dfp, dfr, dfph, "total_signal") == pytest.approx(dfp.pred_fc.sum() + dfr.pred_fc.sum() + dfph.pred_fc.sum())
