@@ -342,3 +342,38 @@ def test_score_fit_batch_matches_reference(eng, golden_files):
         w = eng.score_fit_batch(th, tgt, pred, alpha=0.5, beta=2.0, gamma=0.0, delta=3.0, mu=0.1).cpu().numpy()
         want = np.array([pm.score_fit(th[k], tgt, pred[k], alpha=0.5, beta=2.0, gamma=0.0, delta=3.0, mu=0.1) for k in range(th.shape[0])])
         np.testing.assert_allclose(w, want, rtol=1e-12)
+
+
+def test_batched_multistart_fit_recovers_synthetic_parameters(eng):
+    """paramest core: all starts in lockstep, one launch per iteration.  Data generated by the ORACLE at known parameters must be fitted
+    to (near) zero residual, and the optimum must be at least as good as scipy.optimize.curve_fit on the oracle model from the base start."""
+    from scipy.optimize import curve_fit
+    from phoskintime_amd.paramest import curve_fit_multistart_batch
+    rng = np.random.default_rng(8)
+    model, mid, n = "distmod", pm.DIST, 2
+    true = np.array([1.2, 0.6, 0.9, 0.3, 1.5, 0.7, 0.4, 1.1])
+    y0 = np.ones(4)
+    sol, flat_true = pm.solve_ode(mid, true, y0, n, pm.TIME_POINTS, rtol=1e-11, atol=1e-12)
+    lb, ub = np.full(8, 1e-6), np.full(8, 20.0)
+    base = np.clip(true * np.exp(0.4 * rng.standard_normal(8)), lb, ub)
+    res = curve_fit_multistart_batch(model, y0, n, pm.TIME_POINTS, flat_true, base, (lb, ub), gene="SYN", n_starts=12, seed=1, max_iter=60)
+    assert res.p_all.shape == (12, 8)
+    best_cost = res.cost.min()
+    assert best_cost < 1e-10                                           # noise-free data: the global minimum is 0
+    pred = _np(eng.solve_ode_batch(model, res.popt[None], y0, n, pm.TIME_POINTS).flat)[0]
+    assert np.max(np.abs(pred - flat_true)) < 1e-4
+    f = lambda t, *p: pm.solve_ode(mid, np.asarray(p), y0, n, pm.TIME_POINTS)[1]
+    popt_ref, _ = curve_fit(f, pm.TIME_POINTS, flat_true, p0=base, bounds=(lb, ub), x_scale="jac", maxfev=2000)
+    cost_ref = 0.5 * np.sum((f(None, *popt_ref) - flat_true) ** 2)
+    assert best_cost <= cost_ref * 1.001 + 1e-12
+    assert res.pcov is not None and res.pcov.shape == (8, 8) and np.isfinite(res.score)
+    # ridge term + sigma, randmod in log space: just has to run and improve on the start
+    th = np.array([1.0, 0.5, 0.8, 0.2, 1.0, 0.6, 0.3])                   # randmod n = 1: P = 4 + 1 + 1... (A,B,C,D,S1,D1) -> 6
+    th = th[:6]
+    _, fl = pm.solve_ode(pm.RAND, th, np.ones(3), 1, pm.TIME_POINTS)
+    lb2, ub2 = np.full(6, np.log(1e-8)), np.full(6, np.log(20.0))
+    sig = np.concatenate([np.full(fl.size, 0.5), np.ones(6)])
+    r2 = curve_fit_multistart_batch("randmod", np.ones(3), 1, pm.TIME_POINTS, fl, np.log(th) + 0.3, (lb2, ub2), sigma=sig, lam=1e-3,
+                                    gene="R", n_starts=6, seed=2, max_iter=40)
+    start_cost = 0.5 * np.sum(((_np(eng.solve_ode_batch("randmod", np.exp(np.log(th) + 0.3)[None], np.ones(3), 1, pm.TIME_POINTS).flat)[0] - fl) / 0.5) ** 2)
+    assert r2.cost.min() < start_cost and np.isfinite(r2.score)

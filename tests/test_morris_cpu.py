@@ -88,3 +88,23 @@ def test_compute_Y_matches_oracle():
     sol = rng.uniform(0, 3, (14, 9))
     for metric in pm.METRICS:
         assert _compute_Y(sol, 4, metric) == pytest.approx(pm.compute_Y(sol, 4, metric), rel=1e-14)
+
+
+def test_multistart_candidates_follow_the_reference_recipe():
+    """normest.py:217-265: base first, n/3 clipped Gaussian jitters, stratified uniform for the rest; seeded by (seed + hash(gene))."""
+    from phoskintime_amd.paramest import multistart_candidates
+    lb, ub = np.zeros(5), np.full(5, 20.0)
+    base = np.array([1.0, 2.0, 30.0, 4.0, 5.0])
+    C1 = multistart_candidates("AKT1", base, lb, ub, n_starts=24, seed=42)
+    assert C1.shape == (24, 5) and (C1 >= lb).all() and (C1 <= ub).all()
+    np.testing.assert_array_equal(C1[0], np.clip(base, lb, ub))
+    # restatement with the same RNG calls
+    rng = np.random.default_rng(42 + (sum(ord(c) for c in "AKT1") % 1000003))
+    jit = [np.clip(C1[0] + 0.1 * 20.0 * rng.normal(0.0, 1.0, 5), lb, ub) for _ in range(8)]
+    np.testing.assert_array_equal(C1[1:9], np.stack(jit))
+    strat = C1[9:]
+    for j in range(5):      # stratified: exactly one sample per bin of width 20 / 15 in every coordinate
+        assert sorted((strat[:, j] / (20.0 / 15)).astype(int)) == list(range(15))
+    assert not np.array_equal(C1, multistart_candidates("EGFR", base, lb, ub, n_starts=24, seed=42))
+    with pytest.raises(ValueError):
+        multistart_candidates("x", base, lb, np.full(5, np.inf))
