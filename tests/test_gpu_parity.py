@@ -377,3 +377,24 @@ def test_batched_multistart_fit_recovers_synthetic_parameters(eng):
                                     gene="R", n_starts=6, seed=2, max_iter=40)
     start_cost = 0.5 * np.sum(((_np(eng.solve_ode_batch("randmod", np.exp(np.log(th) + 0.3)[None], np.ones(3), 1, pm.TIME_POINTS).flat)[0] - fl) / 0.5) ** 2)
     assert r2.cost.min() < start_cost and np.isfinite(r2.score)
+
+
+def test_randomised_regimes_against_closed_form(eng):
+    """Sizes up to the 64-lane limit and awkward inputs (log-uniform down to 1e-8, exact zeros, tiny rates, large y0, very long and very
+    short horizons) against the closed-form LTI solution: no flags, band error far inside the gate (measured worst 0.057)."""
+    rng = np.random.default_rng(123)
+    worst = 0.0
+    for model, n in ((0, 1), (0, 15), (0, 47), (0, 62), (1, 2), (1, 29), (1, 62), (2, 1), (2, 3), (2, 5)):
+        P, S = pm.n_params(model, n), pm.n_states(model, n)
+        for kind in ("u20", "log", "tiny", "mixed0", "bigy0", "longt", "shortt"):
+            th = {"u20": lambda: rng.uniform(0, 20, (3, P)), "log": lambda: np.exp(rng.uniform(np.log(1e-8), np.log(20), (3, P))),
+                  "tiny": lambda: rng.uniform(0, 1e-3, (3, P)), "mixed0": lambda: rng.uniform(0, 20, (3, P)) * (rng.uniform(size=(3, P)) > 0.4)
+                  }.get(kind, lambda: rng.uniform(0.05, 5, (3, P)))()
+            y0 = rng.uniform(0, 50, S) if kind == "bigy0" else np.ones(S)
+            t = {"longt": np.array([0.0, 1.0, 1e2, 1e4, 1e5]), "shortt": np.array([0.0, 1e-6, 1e-4, 1e-2])}.get(kind, pm.TIME_POINTS)
+            r = eng.solve_ode_batch(model, th, y0, n, t, clip_nonneg=False)
+            assert not _np(r.status).any(), (model, n, kind)
+            sol = _np(r.sol)
+            for b in range(2):
+                worst = max(worst, pm.band_error(sol[b], pm.solve_exact_lti(model, th[b], y0, n, t)))
+    assert worst <= 0.25
