@@ -7,6 +7,7 @@
 #include "pk_network.hpp"
 #include "pk_network_solve.hpp"
 #include "pk_network_solve_reg.hpp"
+#include "pk_network_solve_reg2.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -217,8 +218,9 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   if (B == 0) return PK_OK;
   if (!x || !y0 || !Y) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
   if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
-  if (n->d.model == 2) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate: the combinatorial topology (model 2) is not integrated yet (rhs / Jacobian are available)");
-  if (n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
+  if (n->d.model == 2 && (n->max_sites > 3 || n->d.N > 256))
+    return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate, combinatorial topology: <= 3 sites per protein (8 phospho states per thread) and N <= 256");
+  if (n->d.model != 2 && n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
   if (n->d.S > 1024 || n->d.N > 512) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate: S <= 1024 states and N <= 512 proteins per network");
   for (int k = 1; k < T; ++k) if (!(t_host[k] > t_host[k - 1])) return pk_ctx_fail(c, PK_ERR_ARG, "t must be strictly increasing");
   pk_solver_opts o;
@@ -265,6 +267,13 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   }
   // Register-resident kernel (one thread per protein) when every block fits its per-thread arrays; opts->linsolve ==
   // PK_LINSOLVE_STRUCTURED forces the LDS kernel (kept as the general fallback and as the A/B reference).
+  if (n->d.model == 2) {
+    const int threads2 = ((n->d.N + 63) / 64) * 64;
+    if (n->max_sites <= 2) hipLaunchKernelGGL((pk::net_solve_reg2_kernel<2>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
+    else                   hipLaunchKernelGGL((pk::net_solve_reg2_kernel<3>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
+    hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e2));
+  }
   const bool reg_ok = n->d.N <= 256 && n->max_sites <= 8 && n->solve_reg_lds_bytes <= 64 * 1024 && o.linsolve != PK_LINSOLVE_STRUCTURED;
   if (reg_ok) {
     const int threads = ((n->d.N + 63) / 64) * 64;

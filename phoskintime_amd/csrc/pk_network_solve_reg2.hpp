@@ -1,0 +1,245 @@
+// pk_network_solve_reg2.hpp -- register-resident network integrator for the COMBINATORIAL topology (model 2):
+// one thread per protein, its 1 + 2^ns states (mRNA + every phospho bit pattern, ns <= NB) in VGPRs.
+//
+// Reference right-hand side: global_model/models.py:323-432 (combinatorial_rhs) under jacspeedup.py:290-343.  Per protein block
+//   d y_m/dt = [m == 0] (C R - D y_0) + sum_{j in m} S_j y_{m ^ j} + sum_{j not in m} E y_{m | j} - loss_m y_m,
+//   loss_m   = sum_{j in m} (E + Dp_j + D) + sum_{j not in m} S_j            (the decay D is charged once per SET BIT, as in the reference)
+// The block Jacobian G = -diag(loss) + F (forward, strictly lower triangular in mask order) + K (back, strictly upper).
+// ROS34PW2 is a W-method, so the linear systems may use the approximate factorisation
+//   g I - J_block  ~=  (D_g - F) D_g^{-1} (D_g - K),   D_g = g I + diag(loss)
+// (defect F D_g^{-1} K = O(h^2) relative): two triangular sweeps over the masks, fully unrolled -- no dense 2^ns x 2^ns solve.
+// Padding (bit j >= ns, masks >= 2^ns) is inert: S_j = 0 there, and every padded state stays exactly 0.
+#pragma once
+#include "pk_network_solve_reg.hpp"
+
+namespace pk {
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void net_solve_reg2_kernel(const NetDev n, const NetSolveArgs A) {
+  using namespace rosw;
+  constexpr int NM = 1 << NB;
+  extern __shared__ __align__(16) double lds[];
+  const int N = n.N, S = n.S;
+  double* Kt = lds;
+  double* Pv = Kt + n.n_K;
+  double* red = Pv + 2 * N;
+  const int nnzT = n.TF_indptr[N];
+  double* tf_dat = red + 24;
+  int32_t* tf_idx = reinterpret_cast<int32_t*>(tf_dat + nnzT);
+  const NetSlices sl(n.n_K, N, n.sites);
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int i = tid;
+  const bool own = i < N;
+  const double* stops = A.stops_p ? A.stops_p : A.stops_v;
+  const int32_t* stop_out = A.stop_out_p ? A.stop_out_p : A.stop_out_v;
+  const double* xb = A.x + b * n.n_var;
+  auto par = [&](int off) { const double v = xb[off]; return A.x_is_raw ? softplus(v) : v; };
+  for (int k = tid; k < nnzT; k += nt) { tf_dat[k] = n.TF_data[k]; tf_idx[k] = n.TF_indices[k]; }
+
+  const int st = own ? n.offset_y[i] : 0, ss = own ? n.offset_s[i] : 0, ns = own ? n.n_sites[i] : 0;
+  const int nst = 1 << ns;
+  const int tf0 = own ? n.TF_indptr[i] : 0, tf1 = own ? n.TF_indptr[i + 1] : 0;
+  const double tfdeg_inv = own ? 1.0 / n.tf_deg[i] : 1.0;
+  const double Ai = own ? par(sl.A + i) : 0.0, Bi = own ? par(sl.B + i) : 1.0, Ci = own ? par(sl.C + i) : 0.0, Di = own ? par(sl.D + i) : 1.0,
+               Ei = own ? par(sl.E + i) : 0.0, ts = par(sl.tf);
+  double Dp[NB], Sr[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { Dp[j] = (j < ns) ? par(sl.Dp + ss + j) : 0.0; Sr[j] = 0.0; }
+  const double* y0 = A.y0 + (A.y0_batched ? b * S : 0);
+  double* Yout = A.Y + b * (size_t)A.T * S;
+  double yR = own ? y0[st] : 0.0, ym[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) ym[m] = (own && m < nst) ? y0[st + 1 + m] : 0.0;
+  auto write_row = [&](int row) {
+    if (!own) return;
+    double* o = Yout + (size_t)row * S + st;
+    o[0] = yR;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) if (m < nst) o[1 + m] = ym[m];
+  };
+  write_row(0);
+
+  auto set_bucket = [&](const int jb) {
+    __syncthreads();
+    for (int k = tid; k < n.n_K; k += nt) Kt[k] = n.kin_Kmat[(size_t)k * n.n_grid + jb] * (A.x_is_raw ? softplus(xb[sl.ck + k]) : xb[sl.ck + k]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double acc = 0.0;
+      if (j < ns) for (int q = n.W_indptr[ss + j]; q < n.W_indptr[ss + j + 1]; ++q) acc += n.W_data[q] * Kt[n.W_indices[q]];
+      Sr[j] = acc;
+    }
+  };
+  // loss_m (depends on the bucket through Sr): recomputed where needed from compile-time mask structure
+  auto loss_of = [&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    double l = 0.0;
+    static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr ((m >> j) & 1) l += Ei + Dp[j] + Di; else l += Sr[j]; });
+    if constexpr (m == 0) l += Di;
+    return l;
+  };
+
+  int buf = 0;
+  auto rhs_block = [&](const double YR, const double (&Y)[NM], double& fR, double (&f)[NM]) {
+    double tot = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) tot += Y[m];                      // the combinatorial RHS ignores driver_map (jacspeedup.py:319-327)
+    if (own) Pv[buf * N + i] = tot;
+    __syncthreads();
+    double acc = 0.0;
+    for (int e = tf0; e < tf1; ++e) acc += tf_dat[e] * Pv[buf * N + tf_idx[e]];
+    buf ^= 1;
+    double v = acc * tfdeg_inv;
+    v = v * net_rcp(1.0 + fabs(v));
+    fR = synth_rate_fast(Ai, ts, v) - Bi * YR;
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double a = (m == 0) ? Ci * YR : 0.0;
+      static_for<NB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr ((m >> j) & 1) a = __builtin_fma(Sr[j], Y[m ^ (1 << j)], a);
+        else a = __builtin_fma(Ei, Y[m | (1 << j)], a);
+      });
+      f[m] = a - loss_of(mc) * Y[m];
+    });
+  };
+
+  double winvR = 1.0, dinv[NM], dg[NM];
+  auto factor = [&](const double g) {
+    winvR = net_rcp(g + Bi);
+    static_for<NM>([&](auto mc) { constexpr int m = decltype(mc)::value; dg[m] = g + loss_of(mc); dinv[m] = net_rcp(dg[m]); });
+  };
+  // x = W~^{-1} r with W~ = (D_g - F) D_g^{-1} (D_g - K):  forward sweep (ascending masks), rescale, backward sweep (descending masks)
+  auto block_solve = [&](const double rR, const double (&r)[NM], double& xR, double (&x)[NM]) {
+    xR = rR * winvR;
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double a = r[m] + ((m == 0) ? Ci * xR : 0.0);
+      static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr ((m >> j) & 1) a = __builtin_fma(Sr[j], x[m ^ (1 << j)], a); });
+      x[m] = a * dinv[m];
+    });
+    static_for<NM>([&](auto mc) {
+      constexpr int m = NM - 1 - decltype(mc)::value;
+      double a = x[m] * dg[m];
+      static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr (!((m >> j) & 1)) a = __builtin_fma(Ei, x[m | (1 << j)], a); });
+      x[m] = a * dinv[m];
+    });
+  };
+
+  __syncthreads();
+  int status = PK_ST_OK, nacc = 0, nrej = 0;
+  double tc = A.t0;
+  int jb = net_bucket(tc, n.kin_grid, n.n_grid);
+  set_bucket(jb);
+  double UR[4], Um[4][NM];
+  double h;
+  {
+    double fR, f[NM];
+    rhs_block(yR, ym, fR, f);
+    auto q = [&](double v, double yv) { return fabs(v) / (A.atol + A.rtol * fabs(yv)); };
+    double d0 = own ? q(yR, yR) : 0.0, d1 = own ? q(fR, yR) : 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) if (own && m < nst) { d0 = fmax(d0, q(ym[m], ym[m])); d1 = fmax(d1, q(f[m], ym[m])); }
+    d0 = block_max(d0, red); d1 = block_max(d1, red);
+    h = (d0 > 1e-5 && d1 > 1e-5) ? 0.01 * d0 / d1 : 1e-6;
+    if (A.h0 > 0.0) h = A.h0;
+    if (!(h > 0.0) || h != h) h = 1e-6;
+  }
+  bool after_reject = false;
+  for (int si = 0; si < A.n_stops && status == PK_ST_OK; ++si) {
+    const double te = stops[si];
+    while (true) {
+      if (nacc + nrej >= A.max_steps) { status |= PK_ST_MAXSTEPS; break; }
+      const bool last = (tc + 1.0001 * h >= te);
+      const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
+      if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; break; }
+      const double hinv = net_rcp(hs);
+      factor(hinv * (1.0 / GAM));
+      double YR = yR, Ym[NM];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) Ym[m] = ym[m];
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        if (sg > 0) {
+          YR = yR;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) Ym[m] = ym[m];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) if (u < sg) {
+            const double a = (sg == 1) ? A21 : (sg == 2 ? (u == 0 ? A31 : A32) : (u == 0 ? A41 : (u == 1 ? A42 : A43)));
+            YR = __builtin_fma(a, UR[u], YR);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) Ym[m] = __builtin_fma(a, Um[u][m], Ym[m]);
+          }
+        }
+        double fR, f[NM];
+        rhs_block(YR, Ym, fR, f);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (u < sg) {
+          const double c = ((sg == 1) ? C21 : (sg == 2 ? (u == 0 ? C31 : C32) : (u == 0 ? C41 : (u == 1 ? C42 : C43)))) * hinv;
+          fR = __builtin_fma(c, UR[u], fR);
+#pragma unroll
+          for (int m = 0; m < NM; ++m) f[m] = __builtin_fma(c, Um[u][m], f[m]);
+        }
+        block_solve(fR, f, UR[sg], Um[sg]);
+      }
+      const double nR = YR + UR[3];
+      double nM[NM];
+      auto q = [&](double ev, double ya, double yb) { return fabs(ev) * net_rcp(A.atol + A.rtol * fmax(fabs(ya), fabs(yb))); };
+      auto mx = [](double a, double c) { return (a > c || a != a) ? a : c; };
+      double e = own ? q(E1 * UR[0] + E2 * UR[1] + E3 * UR[2] + E4 * UR[3], yR, nR) : 0.0;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        nM[m] = Ym[m] + Um[3][m];
+        if (own && m < nst) e = mx(e, q(E1 * Um[0][m] + E2 * Um[1][m] + E3 * Um[2][m] + E4 * Um[3][m], ym[m], nM[m]));
+      }
+      const double err = block_max(e, red);
+      if (err != err || err > 1e300) {
+        ++nrej; after_reject = true; h = 0.1 * hs;
+        double bad = (yR - yR != 0.0 || Ai - Ai != 0.0 || Bi - Bi != 0.0 || Ci - Ci != 0.0 || Di - Di != 0.0 || Ei - Ei != 0.0 || ts - ts != 0.0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) if (ym[m] - ym[m] != 0.0) bad = 1.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) if (Dp[j] - Dp[j] != 0.0 || Sr[j] - Sr[j] != 0.0) bad = 1.0;
+        if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
+        continue;
+      }
+      double fac = cbrt(err) * (1.0 / 0.9);
+      fac = fmax(1.0 / 6.0, fmin(5.0, fac));
+      double hnew = hs * net_rcp(fac);
+      if (err <= 1.0) {
+        ++nacc;
+        yR = nR;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) ym[m] = nM[m];
+        tc += hs;
+        if (after_reject) hnew = fmin(hnew, hs);
+        after_reject = false;
+        if (last) { tc = te; h = (hs < h) ? fmax(hnew, h) : hnew; break; }
+        h = hnew;
+      } else {
+        ++nrej; after_reject = true;
+        h = hnew;
+      }
+    }
+    if (status != PK_ST_OK) break;
+    const int row = stop_out[si];
+    if (row >= 0) write_row(row);
+    const int jn = net_bucket(tc, n.kin_grid, n.n_grid);
+    if (jn != jb) { jb = jn; set_bucket(jb); }
+  }
+  if (status != PK_ST_OK && own) {
+    const double qnan = __builtin_nan("");
+    for (int si = 0; si < A.n_stops; ++si) {
+      const int row = stop_out[si];
+      if (row >= 0 && !(stops[si] <= tc)) { double* o = Yout + (size_t)row * S + st; for (int k = 0; k < 1 + nst; ++k) o[k] = qnan; }
+    }
+  }
+  if (tid == 0) {
+    if (A.status) A.status[b] = status;
+    if (A.n_steps) { A.n_steps[2 * b] = nacc; A.n_steps[2 * b + 1] = nrej; }
+  }
+}
+
+}  // namespace pk

@@ -91,7 +91,7 @@ def test_network_create_rejects_bad_topology():
         NetworkEngine.from_npz(bad)
 
 
-@pytest.mark.parametrize("f", [x for x in GOLD if "_m2_" not in x.name], ids=lambda f: f.stem)
+@pytest.mark.parametrize("f", GOLD, ids=lambda f: f.stem)
 def test_network_simulate_within_band_of_reference_lsoda(f):
     """simulate_odeint batched (ROS34PW2, block-diagonal W) against the reference's LSODA run at 1e-12 (`Y_tight`); the reference's own
     production tolerance (1e-8 / 1e-8, `Y_lsoda8`) is checked to be no closer to the truth than we are required to be."""
@@ -142,8 +142,17 @@ def test_network_simulate_edge_cases():
     with pytest.raises(PhoskinError):
         eng.simulate_batch(X, [0.0, 1.0, 1.0])
     eng.close()
-    g2 = np.load([x for x in GOLD if x.name == "network_m2_small.npz"][0])
-    e2 = NetworkEngine.from_npz(g2)
+    # combinatorial topology: supported up to 3 sites per protein; a 4-site protein is refused, not mis-integrated
+    from phoskintime_amd.global_model import synthetic
+    net4 = synthetic.make_network(N=8, total_sites=12, n_K=4, n_tf_edges=10, model=0, seed=5)
+    net4["model"] = 2
+    ns = net4["n_sites"].copy(); ns[:] = 1; ns[0] = 4
+    net4["n_sites"] = ns
+    net4["offset_s"] = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int32)
+    net4["offset_y"] = np.concatenate([[0], np.cumsum(1 + (1 << ns.astype(np.int64)))[:-1]]).astype(np.int32)
+    tot = int(ns.sum())
+    net4["W_indptr"] = np.arange(tot + 1, dtype=np.int32); net4["W_indices"] = np.zeros(tot, np.int32); net4["W_data"] = np.ones(tot)
+    e2 = NetworkEngine(**net4)
     with pytest.raises(PhoskinError):
         e2.simulate_batch(np.ones((1, e2.n_var)), [0.0, 1.0])
     e2.close()

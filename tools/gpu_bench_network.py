@@ -7,7 +7,7 @@ from phoskintime_amd.global_model import synthetic
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    for model in (0, 1, 4):
+    for model in (0, 1, 4, 2):
         net = synthetic.make_network(model=model)
         eng = NetworkEngine(**net)
         X = synthetic.random_candidates(net, B, seed=1)
