@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--linsolve", default="auto")
     ap.add_argument("--method", default="lrp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-network", action="store_true", help="skip the secondary network-path measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="replicas in the CPU baseline sample (0 = 128 per core)")
     args = ap.parse_args()
 
@@ -173,6 +174,25 @@ def main():
                                    "sample": "first %d replicas of the same batch; reference call shape (SciPy odeint/LSODA at default "
                                              "tolerances -> clip -> flat) on the oracle's numpy-vectorised distmod RHS, one process per core; "
                                              "wall %.1f s" % (nsamp, wall)}
+        if not args.no_cpu_baseline and world == 1 and not args.no_network:
+            # secondary evidence (NOT the metric): the network path of BASELINE configs 4 / 5 on a synthetic network of their shape
+            try:
+                from phoskintime_amd.global_model import NetworkEngine, synthetic
+                net = synthetic.make_network(model=0)
+                eng = NetworkEngine(**net)
+                Xn = torch.as_tensor(synthetic.random_candidates(net, 8192, seed=1), device=dev)
+                tn = np.unique(np.concatenate([net["kin_grid"], [15.0]]))
+                eng.simulate_batch(Xn[:256], tn, rtol=1e-5, atol=1e-7); torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                Yn, stn, nsn = eng.simulate_batch(Xn, tn, rtol=1e-5, atol=1e-7); torch.cuda.synchronize(dev)
+                dtn = time.perf_counter() - t1
+                res["network_secondary"] = {"workload": "synthetic config-5-shaped network (N=100 proteins, 300 sites, S=500 states, n_var=841), "
+                                                        "8192 candidates, simulate at the reference's sensitivity tolerance rtol 1e-5 / atol 1e-7",
+                                            "candidates_per_s": 8192 / dtn, "ms": 1e3 * dtn, "mean_steps": float(nsn[:, 0].double().mean()),
+                                            "flagged": int((stn != 0).sum()), "integrator": "ROS34PW2 Rosenbrock-W, block-diagonal Jacobian"}
+                eng.close()
+            except Exception as e:  # never let the secondary line break the metric
+                res["network_secondary"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()

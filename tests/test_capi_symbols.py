@@ -67,3 +67,16 @@ def test_no_cpu_fallback_without_gpu():
         batch.solve_ode_batch(0, np.ones((1, 12)), np.ones(6), 4, [0.0, 1.0])
     src = "".join(p.read_text() for p in (ROOT / "phoskintime_amd").rglob("*.py"))
     assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", "")
+
+
+def test_header_is_valid_plain_c(tmp_path):
+    """include/phoskin.h is the C ABI: it must compile as C (no C++-isms) and expose the structs with the sizes the binding assumes."""
+    import subprocess
+    from phoskintime_amd import _capi
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "phoskin.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(pk_solver_opts), sizeof(pk_network_desc), '
+                   'sizeof(pk_loss_data)); return 0;}\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out] == [C.sizeof(_capi.SolverOpts), C.sizeof(_capi.NetworkDesc), C.sizeof(_capi.LossData)]
