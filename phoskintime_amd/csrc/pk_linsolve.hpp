@@ -118,6 +118,7 @@ struct ArrowSolver {
 };
 
 // SUCC: parallel cyclic reduction.  Level d (1, 2, 4, ...): row i eliminates its couplings to i-d and i+d.
+// Neighbour values come through gshift (DPP row shifts for G <= 16: no LDS-crossbar trip), which returns 0 outside the group.
 template <int G>
 struct TridiagSolver {
   static constexpr int LV = (G == 8) ? 3 : (G == 16) ? 4 : (G == 32) ? 5 : 6;
@@ -132,15 +133,15 @@ struct TridiagSolver {
       constexpr int l = decltype(lc)::value;
       constexpr int d = 1 << l;
       const bool hl = (row - d >= 0), hu = (row + d < G);
-      const double b_m = gshfl<G>(b, row - d, lane), b_p = gshfl<G>(b, row + d, lane);
-      const double lo_m = gshfl<G>(lo, row - d, lane), up_m = gshfl<G>(up, row - d, lane);
-      const double lo_p = gshfl<G>(lo, row + d, lane), up_p = gshfl<G>(up, row + d, lane);
+      const double b_m = gshift<G, d>(b, row, lane), b_p = gshift<G, -d>(b, row, lane);
+      const double lo_m = gshift<G, d>(lo, row, lane), up_m = gshift<G, d>(up, row, lane);
+      const double lo_p = gshift<G, -d>(lo, row, lane), up_p = gshift<G, -d>(up, row, lane);
       const double k1 = hl ? lo * fast_rcp(b_m) : 0.0;
       const double k2 = hu ? up * fast_rcp(b_p) : 0.0;
       kl[l] = k1; ku[l] = k2;
-      b = b - k1 * (hl ? up_m : 0.0) - k2 * (hu ? lo_p : 0.0);
-      lo = hl ? -k1 * lo_m : 0.0;
-      up = hu ? -k2 * up_p : 0.0;
+      b = b - k1 * up_m - k2 * lo_p;                     // shifted-in values are 0 outside the group
+      lo = -k1 * lo_m;
+      up = -k2 * up_p;
     });
     binv = fast_rcp(b);
   }
@@ -148,8 +149,8 @@ struct TridiagSolver {
     static_for<LV>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       constexpr int d = 1 << l;
-      const double r_m = gshfl<G>(r, row - d, lane), r_p = gshfl<G>(r, row + d, lane);
-      r = __builtin_fma(-kl[l], r_m, r);                // kl / ku are 0 where the neighbour does not exist
+      const double r_m = gshift<G, d>(r, row, lane), r_p = gshift<G, -d>(r, row, lane);
+      r = __builtin_fma(-kl[l], r_m, r);
       r = __builtin_fma(-ku[l], r_p, r);
     });
     return r * binv;

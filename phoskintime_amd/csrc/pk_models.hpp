@@ -89,10 +89,10 @@ __device__ __forceinline__ double rhs(const RowCoef& c, const double y, const in
     f = __builtin_fma(c.c2, R, f);
     return (row == 1) ? f + sumsites : f;
   } else if constexpr (MODEL == M_SUCC) {
-    const double lo = gshfl<G>(y, row - 1, lane);
-    const double hi = gshfl<G>(y, row + 1, lane);
+    const double lo = gshift<G, 1>(y, row, lane);       // y[row - 1], 0 outside the group
+    const double hi = gshift<G, -1>(y, row, lane);      // y[row + 1]
     double f = __builtin_fma(c.dg, y, c.bias);
-    f = __builtin_fma(c.c1, (row >= 1) ? lo : 0.0, f);
+    f = __builtin_fma(c.c1, lo, f);
     f = __builtin_fma(c.c2, (row + 1 < S) ? hi : 0.0, f);
     return f;
   } else {

@@ -67,6 +67,27 @@ __device__ __forceinline__ double gshfl(double v, int src, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// value of group lane (row - D) [D > 0] or (row + |D|) [D < 0]; lanes whose source falls outside the group get 0.
+// G <= 16: DPP row_shr / row_shl (zero fill at the 16-lane row edge; for G == 8 the half-row edge is masked explicitly so that
+// nothing -- in particular no NaN of a failed neighbour replica -- leaks across groups).  G >= 32: ds_bpermute.
+template <int G, int D>
+__device__ __forceinline__ double gshift(double v, int row, int lane) {
+  constexpr int AD = D > 0 ? D : -D;
+  static_assert(AD >= 1 && AD < G, "shift distance");
+  const bool inside = (D > 0) ? (row - AD >= 0) : (row + AD < G);
+  if constexpr (G <= 16 && AD < 16) {
+    constexpr int ctrl = (D > 0 ? 0x110 : 0x100) + AD;              // row_shr:AD / row_shl:AD
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    const double r = __hiloint2double(hi, lo);
+    if constexpr (G == 16) return r;                                  // DPP already zero-fills at the row edge
+    else return inside ? r : 0.0;
+  } else {
+    const double r = gshfl<G>(v, row - D, lane);
+    return inside ? r : 0.0;
+  }
+}
+
 // ---- butterfly partners.  Levels 1..8 stay in the VALU (DPP: quad_perm / row_half_mirror / row_mirror, ~1 issue slot
 // per dword, no LDS-crossbar trip); level 16 uses ds_swizzle, level 32 ds_bpermute.  Mirrors instead of XORs at levels
 // 4 and 8 pair the same sub-groups, and every lane of a group still ends with the bit-identical result (fp add and
