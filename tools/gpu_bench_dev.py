@@ -44,9 +44,11 @@ if __name__ == '__main__':
         run(0, 30, 65536, 'bdf2', 'structured')
         run(0, 30, 8192, 'bdf2', 'dense')
     if which in ('all', 'c2'):
+        run(1, 14, 4096, 'lrp8', 'auto')
+        run(1, 14, 4096, 'lrp8', 'auto', 0.05, 2.0)
         run(1, 14, 4096, 'rodas4', 'structured')
-        run(1, 14, 4096, 'rodas4', 'dense')
-        run(1, 14, 65536, 'rodas4', 'structured')
+        run(1, 14, 4096, 'bdf2', 'structured')
+        run(1, 14, 65536, 'lrp8', 'auto')
         run(1, 14, 4096, 'rk4', 'auto', 0.05, 2.0, rk4_h=0.02)
         run(1, 14, 4096, 'rk4', 'auto', 0.0, 20.0, rk4_h=0.01)
     if which in ('all', 'misc'):
