@@ -174,6 +174,17 @@ def main():
                                    "sample": "first %d replicas of the same batch; reference call shape (SciPy odeint/LSODA at default "
                                              "tolerances -> clip -> flat) on the oracle's numpy-vectorised distmod RHS, one process per core; "
                                              "wall %.1f s" % (nsamp, wall)}
+        if not args.no_cpu_baseline and world == 1:
+            # the SAME algorithm (LRP8 + arrow elimination) in scalar C on the host cores: separates what the method buys from what the GPU buys
+            try:
+                from oracle import lrp8_cpu
+                cores = min(os.cpu_count() or 1, 16)
+                nsamp2 = 2048 * cores
+                rate2 = lrp8_cpu.cpu_rate(theta_h[:nsamp2], n_sites, np.ones(S), tgrid, cores)
+                res["cpu_same_algorithm"] = {"value": rate2, "unit": "replicas/s", "cores": cores, "kind": "port",
+                                             "sample": "first %d replicas; oracle/lrp8_dist.c (gcc -O2, scalar), one process per core" % nsamp2}
+            except Exception as e:
+                res["cpu_same_algorithm"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and not args.no_network:
             # secondary evidence (NOT the metric): the network path of BASELINE configs 4 / 5 on a synthetic network of their shape
             try:

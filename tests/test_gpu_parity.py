@@ -398,3 +398,15 @@ def test_randomised_regimes_against_closed_form(eng):
             for b in range(2):
                 worst = max(worst, pm.band_error(sol[b], pm.solve_exact_lti(model, th[b], y0, n, t)))
     assert worst <= 0.25
+
+
+def test_gpu_kernel_matches_independent_c_implementation_of_the_same_algorithm(eng, golden_files):
+    """dist_fast (LRP8) against oracle/lrp8_dist.c: same method, same controller -- agreement far inside the band, equal step counts."""
+    from oracle import lrp8_cpu
+    g, model, n = _load([x for x in golden_files if x.name == "protein_distmod_n30_c3bounds.npz"][0])
+    r = eng.solve_ode_batch(model, g["theta"], g["y0"][0], n, g["t"], clip_nonneg=False)
+    sol_c, st_c, ns_c = lrp8_cpu.solve_batch(g["theta"], n, g["y0"][0], g["t"])
+    assert not st_c.any() and not _np(r.status).any()
+    assert pm.band_error(_np(r.sol), sol_c) <= 0.02
+    steps_gpu = _np(r.n_steps)[:, 0]
+    assert np.abs(steps_gpu - ns_c[:, 0]).max() <= 2          # the error estimate differs in the last bits only
