@@ -1,6 +1,6 @@
 // pk_linsolve.hpp -- solvers for the implicit stage systems  (g I - J) x = r,  one replica per lane group.
 //
-//   Dense<G>            any model: W row-per-lane in VGPRs, LU by cross-lane broadcast (pk_wave.hpp)
+//   DenseInv<G>         any model: W row-per-lane in VGPRs, Gauss-Jordan inverse by cross-lane broadcast (pk_wave.hpp)
 //   Arrow<G>  (DIST)    J is an arrow matrix: eliminate the site rows, one group reduction per solve
 //   Tridiag<G> (SUCC)   J is tridiagonal: parallel cyclic reduction, log2(G) neighbour exchanges per solve
 #pragma once
@@ -18,48 +18,10 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
-template <int MODEL, int G>
-struct DenseSolver {
-  double a[G];
-  double dinv;
-  __device__ __forceinline__ void factor(const RowCoef& c, const double g, const int S, const int row, const int lane) {
-    fill_w_row<MODEL, G>(a, c, g, S, row);
-    dinv = 1.0;
-    static_for<G>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const double piv = bcast<G, k>(a[k]);
-      const double rp = fast_rcp(piv);
-      if (row == k) dinv = rp;
-      if constexpr (k + 1 < G) {
-        const double l = (row > k) ? a[k] * rp : 0.0;   // l == 0 leaves rows <= k untouched
-        if (row > k) a[k] = l;
-        static_for<G - 1 - k>([&](auto jc) {
-          constexpr int j = k + 1 + decltype(jc)::value;
-          const double u = bcast<G, k>(a[j]);
-          a[j] = __builtin_fma(-l, u, a[j]);
-        });
-      }
-    });
-  }
-  __device__ __forceinline__ double solve(double x, const int S, const int row, const int lane) const {
-    static_for<G - 1>([&](auto kc) {                     // L z = x (unit lower)
-      constexpr int k = decltype(kc)::value;
-      const double xk = bcast<G, k>(x);
-      if (row > k) x = __builtin_fma(-a[k], xk, x);
-    });
-    static_for<G - 1>([&](auto kc) {                     // U x = z
-      constexpr int k = G - 1 - decltype(kc)::value;
-      const double xk = bcast<G, k>(x * dinv);
-      if (row < k) x = __builtin_fma(-a[k], xk, x);
-    });
-    return x * dinv;
-  }
-};
-
 // Dense, explicit inverse: in-register Gauss-Jordan (no pivoting, same M-matrix argument), then every solve is a
-// mat-vec whose G broadcasts are independent of each other -- no 2G-long dependent chain as in the triangular solves
-// of DenseSolver, which is what bounds that variant (latency of the cross-lane broadcast, measured).  The price is
-// ~2x the factorisation flops; with 6-8 solves per factorisation (resolvent-form steps) the inverse wins clearly.
+// mat-vec whose G broadcasts are independent of each other.  The first version of this solver (LU + two triangular solves per
+// right-hand side) was bound by the 2G-long dependent chain of cross-lane broadcasts: 363 ms vs 29 ms on config 3.
+// The price is ~2x the factorisation flops; with 6-8 solves per factorisation (resolvent-form steps) the inverse wins clearly.
 template <int MODEL, int G>
 struct DenseInvSolver {
   double a[G];           // row `row` of W, then of W^{-1}

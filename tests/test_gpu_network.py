@@ -323,3 +323,22 @@ def test_dropin_simulate_odeint_and_measure_with_system_object():
     assert np.allclose(dfp[dfp["time"] == 0.0]["pred_fc"], 1.0) and np.allclose(dfr[dfr["time"] == 4.0]["pred_fc"], 1.0)
     from phoskintime_amd.global_model.sensitivity import _compute_scalar_metric
     assert _compute_scalar_metric(dfp, dfr, dfph, "total_signal") == pytest.approx(dfp.pred_fc.sum() + dfr.pred_fc.sum() + dfph.pred_fc.sum())
+
+
+def test_network_long_output_grid_uses_the_buffered_stop_list():
+    """More than 64 landing points (e.g. the reference's 1000-point steady-state grid, global_model/analysis.py:29-56) go through the
+    per-network device buffer instead of the by-value kernel argument: same trajectory at the shared time points."""
+    from phoskintime_amd.global_model import NetworkEngine
+    g = np.load([x for x in GOLD if x.name == "network_m1_small.npz"][0])
+    eng = NetworkEngine.from_npz(g)
+    X = np.stack([_x(eng, g, k) for k in range(2)])
+    dense_t = np.unique(np.concatenate([np.logspace(-3, np.log10(960.0), 150), g["t_eval"]]))
+    dense_t = np.concatenate([[0.0], dense_t[dense_t > 0]])
+    Yd, sd, _ = eng.simulate_batch(X, dense_t)
+    Ys, ss, _ = eng.simulate_batch(X, g["t_eval"])
+    assert not sd.cpu().numpy().any() and dense_t.size > 64
+    idx = [int(np.where(dense_t == t)[0][0]) for t in g["t_eval"]]
+    a, b = Yd.cpu().numpy()[:, idx, :], Ys.cpu().numpy()
+    assert np.max(np.abs(a - b) / (1e-8 + 1e-6 * np.abs(b))) <= 0.3
+    assert np.isfinite(Yd.cpu().numpy()).all()
+    eng.close()
