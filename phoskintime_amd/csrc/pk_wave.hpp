@@ -38,8 +38,8 @@ __device__ __forceinline__ double bcast(double v) {
     hi = __builtin_amdgcn_readlane(hi, K);
   } else if constexpr (G == 16) {
     // DPP row_newbcast:K -- lane K of each 16-lane row to the whole row; stays in the VALU
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xf, 0xf, true);
   } else if constexpr (G == 8) {
     // two bank-masked row_newbcasts: lanes 0-7 of a row take lane K, lanes 8-15 take lane 8 + K
     const int l0 = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0x3, false);
@@ -47,8 +47,8 @@ __device__ __forceinline__ double bcast(double v) {
     lo = __builtin_amdgcn_update_dpp(l0, lo, 0x150 + 8 + K, 0xf, 0xc, false);
     hi = __builtin_amdgcn_update_dpp(h0, hi, 0x150 + 8 + K, 0xf, 0xc, false);
   } else if constexpr (G == 4) {
-    lo = __builtin_amdgcn_update_dpp(0, lo, K * 0x55, 0xf, 0xf, false);      // quad_perm [K,K,K,K]
-    hi = __builtin_amdgcn_update_dpp(0, hi, K * 0x55, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, K * 0x55, 0xf, 0xf, true);      // quad_perm [K,K,K,K]
+    hi = __builtin_amdgcn_update_dpp(hi, hi, K * 0x55, 0xf, 0xf, true);
   } else {
     // bit-mask mode: src_lane = ((lane & and_mask) | or_mask) ^ xor_mask within each 32-lane half
     constexpr int pat = ((32 - G) & 0x1f) | (K << 5);
@@ -77,8 +77,9 @@ __device__ __forceinline__ double gshift(double v, int row, int lane) {
   const bool inside = (D > 0) ? (row - AD >= 0) : (row + AD < G);
   if constexpr (G <= 16 && AD < 16) {
     constexpr int ctrl = (D > 0 ? 0x110 : 0x100) + AD;              // row_shr:AD / row_shl:AD
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    const int l_ = __double2loint(v), h_ = __double2hiint(v);
+    const int lo = __builtin_amdgcn_update_dpp(l_, l_, ctrl, 0xf, 0xf, true);       // bound_ctrl: lanes shifted in from outside the row read 0
+    const int hi = __builtin_amdgcn_update_dpp(h_, h_, ctrl, 0xf, 0xf, true);
     const double r = __hiloint2double(hi, lo);
     if constexpr (G == 16) return r;                                  // DPP already zero-fills at the row edge
     else return inside ? r : 0.0;
@@ -92,10 +93,13 @@ __device__ __forceinline__ double gshift(double v, int row, int lane) {
 // per dword, no LDS-crossbar trip); level 16 uses ds_swizzle, level 32 ds_bpermute.  Mirrors instead of XORs at levels
 // 4 and 8 pair the same sub-groups, and every lane of a group still ends with the bit-identical result (fp add and
 // max are commutative, and the tree shape is the same for all lanes).
+// `old` = the source itself and bound_ctrl = 1: every lane of these permutations has a valid source, so no zero-initialised
+// destination register (an extra v_mov per dword) is needed
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
