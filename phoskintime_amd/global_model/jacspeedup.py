@@ -1,0 +1,73 @@
+"""Drop-in names of the reference's ``global_model/jacspeedup.py`` (the odeint calling convention) on the MI355X engine.
+
+  rhs_odeint(y, t, *args)            jacspeedup.py:392-394   -> dy/dt, args = System.odeint_args() (23-tuple; 27-tuple for model 2)
+  fd_jacobian_odeint(y, t, *args)    jacspeedup.py:585-588   -> J row-major; ANALYTIC here (the reference finite-differences)
+  solve_custom(sys, y0, t_eval, rtol, atol)   jacspeedup.py:31-64   -> Y [T, S]; the reference's opt-in Numba RK45 slot, served by the
+                                                                     engine's Rosenbrock-W integrator (same contract, stiff-safe)
+  build_S_cache_into(S_out, W_indptr, W_indices, W_data, kin_Kmat, c_k)   jacspeedup.py:117-145   (host arithmetic, once per candidate)
+
+Engines are cached per topology (keyed by the identity of the static arrays inside ``args``), parameters travel per call."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import config
+from .engine import NetworkEngine
+
+_cache: dict = {}
+
+
+def _engine_and_candidate(args, model):
+    if model == 2:
+        # (c_k, A, B, C, D, Dp, E, tf_scale, kin_grid, S_cache, TF_indptr, TF_indices, TF_data, n_TF, offset_y, offset_s, n_sites, n_states,
+        #  trans_from, trans_to, trans_site, trans_off, trans_n, tf_deg, driver_map, P_vec_work, TF_in_work)        network.py:478-506
+        (c_k, A, B, Cc, D, Dp, E, tfs, grid, S_cache, tp, ti, td, nT, oy, os_, ns, nst, *_rest) = args[:18] + tuple(args[18:])
+        tf_deg, drv = args[23], args[24]
+        sites = int(np.sum(ns))
+        key = ("m2", id(S_cache), id(tp), id(oy))
+        ent = _cache.get(key)
+        S_cache = np.asarray(S_cache, float)
+        if ent is None or not np.array_equal(ent[1], S_cache):
+            # the 27-tuple carries S_cache = W (Kmat * c_k) instead of W and Kmat: feed it as "one pseudo-kinase per site" with W = I
+            eng = NetworkEngine(2, oy, os_, ns, np.arange(sites + 1, dtype=np.int32), np.arange(sites, dtype=np.int32), np.ones(sites),
+                                tp, ti, td, tf_deg, np.full(len(oy), -1, np.int32), grid, S_cache if sites else np.ones((1, len(grid))))
+            ent = _cache[key] = (eng, S_cache.copy())
+        eng = ent[0]
+        x = eng.pack_params(np.ones(eng.n_K), A, B, Cc, D, Dp, E, tfs)
+        return eng, x
+    (c_k, A, B, Cc, D, Dp, E, tfs, grid, kmat, wp, wi, wd, nW, tp, ti, td, nT, oy, os_, ns, deg, drv) = args
+    key = (model, id(wp), id(tp), id(oy), id(kmat))
+    ent = _cache.get(key)
+    if ent is None or not np.array_equal(ent[1], drv):
+        ent = _cache[key] = (NetworkEngine.from_odeint_args(args, model), np.array(drv, copy=True))
+    eng = ent[0]
+    return eng, eng.pack_params(c_k, A, B, Cc, D, Dp, E, tfs)
+
+
+def rhs_odeint(y, t, *args):
+    """dy/dt with the reference's odeint calling convention; the kinetic topology is ``config.MODEL`` (import-time in the reference)."""
+    eng, x = _engine_and_candidate(args, config.MODEL)
+    return eng.rhs_batch(x[None, :], np.asarray(y, float), float(t)).cpu().numpy()[0]
+
+
+def fd_jacobian_odeint(y, t, *args):
+    """J [S, S] row-major (col_deriv=False as in simulate.py:75).  Analytic: agrees with the reference's forward differences to their error."""
+    eng, x = _engine_and_candidate(args, config.MODEL)
+    return eng.jacobian_batch(x[None, :], np.asarray(y, float), float(t)).cpu().numpy()[0]
+
+
+def solve_custom(sys, y0, t_eval, rtol, atol):
+    """Y [T, S] for the system's current parameters from an explicit y0 (reference: adaptive RK45 dispatch, jacspeedup.py:31-64)."""
+    from .simulate import engine_for, candidate_of
+    eng = engine_for(sys)
+    Y, _, _ = eng.simulate_batch(candidate_of(sys, eng)[None, :], np.asarray(t_eval, float), y0=np.asarray(y0, float), rtol=rtol, atol=atol)
+    return np.ascontiguousarray(Y[0].cpu().numpy())
+
+
+def build_S_cache_into(S_out, W_indptr, W_indices, W_data, kin_Kmat, c_k):
+    """S_out[site, bin] = sum_k W[site, k] * kin_Kmat[k, bin] * c_k[k]   (model 2 pre-computation, once per candidate)."""
+    scaled = np.asarray(kin_Kmat, float) * np.asarray(c_k, float)[:, None]
+    for i in range(S_out.shape[0]):
+        a, b = W_indptr[i], W_indptr[i + 1]
+        S_out[i, :] = np.asarray(W_data[a:b], float) @ scaled[np.asarray(W_indices[a:b])] if b > a else 0.0
+    return S_out

@@ -342,3 +342,34 @@ def test_network_long_output_grid_uses_the_buffered_stop_list():
     assert np.max(np.abs(a - b) / (1e-8 + 1e-6 * np.abs(b))) <= 0.3
     assert np.isfinite(Yd.cpu().numpy()).all()
     eng.close()
+
+
+@pytest.mark.parametrize("m", [0, 1, 2, 4])
+def test_dropin_jacspeedup_odeint_convention(m):
+    """rhs_odeint / fd_jacobian_odeint with the reference's odeint_args tuples (23 entries; 27 with S_cache for the combinatorial
+    topology), build_S_cache_into, solve_custom."""
+    from phoskintime_amd.global_model import jacspeedup as js, config as gcfg
+    g = np.load([x for x in GOLD if x.name == f"network_m{m}_small.npz"][0])
+    gcfg.MODEL = m
+    k = 1
+    N = int(g["N"])
+    if m == 2:
+        S_cache = np.zeros((int(g["total_sites"]), g["kin_grid"].size))
+        js.build_S_cache_into(S_cache, g["W_indptr"], g["W_indices"], g["W_data"], g["kin_Kmat"], g["c_k"][k])
+        np.testing.assert_allclose(S_cache, g["S_cache_set1"], rtol=1e-14)
+        args = (g["c_k"][k], g["A_i"][k], g["B_i"][k], g["C_i"][k], g["D_i"][k], g["Dp_i"][k], g["E_i"][k], float(g["tf_scale"][k]), g["kin_grid"],
+                S_cache, g["TF_indptr"], g["TF_indices"], g["TF_data"], N, g["offset_y"], g["offset_s"], g["n_sites"], g["n_states"],
+                g["trans_from"], g["trans_to"], g["trans_site"], g["trans_off"], g["trans_n"], g["tf_deg"], g["driver_map"], np.zeros(N), np.zeros(N))
+    else:
+        args = (g["c_k"][k], g["A_i"][k], g["B_i"][k], g["C_i"][k], g["D_i"][k], g["Dp_i"][k], g["E_i"][k], float(g["tf_scale"][k]), g["kin_grid"],
+                g["kin_Kmat"], g["W_indptr"], g["W_indices"], g["W_data"], int(g["total_sites"]), g["TF_indptr"], g["TF_indices"], g["TF_data"], N,
+                g["offset_y"], g["offset_s"], g["n_sites"], g["tf_deg"], g["driver_map"])
+    for ti, t in enumerate(g["t_probe"][:6]):
+        dy = js.rhs_odeint(g["y_rand"][k], float(t), *args)
+        np.testing.assert_allclose(dy, g["rhs_rand"][k, ti], rtol=1e-12, atol=1e-12)
+    J = js.fd_jacobian_odeint(g["y_rand"][k], float(g["fd_jac_t"]), *args)
+    assert J.shape == g["fd_jac"][k].shape and np.abs(J - g["fd_jac"][k]).max() <= 2e-6 * (1.0 + np.abs(g["fd_jac"][k]).max())
+    if m != 2:
+        sysm, idx = _fake_system(g, k)
+        Y = js.solve_custom(sysm, g["y0"], g["t_eval"], 1e-7, 1e-9)
+        assert np.max(np.abs(Y - g["Y_tight"][k]) / (1e-8 + 1e-6 * np.abs(g["Y_tight"][k]))) <= 0.5
