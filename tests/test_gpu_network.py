@@ -373,3 +373,32 @@ def test_dropin_jacspeedup_odeint_convention(m):
         sysm, idx = _fake_system(g, k)
         Y = js.solve_custom(sysm, g["y0"], g["t_eval"], 1e-7, 1e-9)
         assert np.max(np.abs(Y - g["Y_tight"][k]) / (1e-8 + 1e-6 * np.abs(g["Y_tight"][k]))) <= 0.5
+
+
+def test_population_evaluation_matches_elementwise_restatement():
+    """GlobalODEBatch.evaluate(X_raw) == the oracle's restatement of GlobalODE_MOO._evaluate applied candidate by candidate (on the GPU
+    trajectories: the simulation itself is checked elsewhere), including the fail_value of a candidate whose simulation is flagged."""
+    from phoskintime_amd.global_model import NetworkEngine
+    from phoskintime_amd.global_model.optproblem import GlobalODEBatch
+    g = np.load([x for x in GOLD if x.name == "network_m0_small.npz"][0])
+    gl = np.load(Path(__file__).resolve().parent / "golden" / "network_loss_m0.npz")
+    eng = NetworkEngine.from_npz(g)
+    net = nm.Network.from_npz(g)
+    ld = {k: gl[k] for k in gl.files}
+    keys = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i", "tf_scale")
+    defaults = {k: (g[k][0] if k != "tf_scale" else float(g[k][0])) for k in keys}
+    lam = dict(protein=1.0, rna=2.0, phospho=0.5, prior=0.3)
+    prob = GlobalODEBatch(eng, None, ld, defaults, lam, g["t_eval"], rtol=1e-7, atol=1e-9)
+    Xphys = np.stack([_x(eng, g, k) for k in range(4)])
+    Xraw = np.log(np.expm1(np.maximum(Xphys, 1e-12)))                 # inv_softplus (utils.py:245-253)
+    Xraw[3, 2] = np.nan                                               # a broken candidate
+    F = prob.evaluate(Xraw)
+    assert F.shape == (4, 3) and (F[3] == 1e12).all()
+    Y, _, _ = eng.simulate_batch(Xraw[:3], g["t_eval"], raw=True, rtol=1e-7, atol=1e-9)
+    Y = Y.cpu().numpy()
+    dflt = eng.pack_params(*(defaults[k] for k in keys))
+    for k in range(3):
+        xp = np.where(Xraw[k] > 20, Xraw[k], np.log1p(np.exp(Xraw[k])))
+        want = nm.objectives(net, xp, dflt, Y[k], ld, 0, lam)
+        np.testing.assert_allclose(F[k], want, rtol=1e-10)
+    prob.close(); eng.close()
