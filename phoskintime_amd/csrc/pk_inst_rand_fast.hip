@@ -1,5 +1,7 @@
 // Instantiations + launcher of the random-model throughput kernel (pk_rand_fast.hpp).
 #include "pk_rand_fast.hpp"
+#include "pk_rand_fast2.hpp"
+#include <cstdlib>
 #include "pk_launch.hpp"
 
 namespace pk {
@@ -19,7 +21,14 @@ void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {
     case 2: launch_nb<2>(a, method, st); break;
     case 3: launch_nb<3>(a, method, st); break;
     case 4: launch_nb<4>(a, method, st); break;
-    default: launch_nb<5>(a, method, st); break;
+    default: {
+      // n = 5: two rows per lane in 16-lane groups (DPP broadcasts); PK_RAND5_G32=1 selects the one-row-per-lane 32-lane kernel (A/B)
+      static const bool g32 = getenv("PK_RAND5_G32") && atoi(getenv("PK_RAND5_G32")) != 0;
+      if (g32) { launch_nb<5>(a, method, st); break; }
+      const long long nblk = (a.B + 15) / 16;
+      if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+      else                          hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+    } break;
   }
 }
 
