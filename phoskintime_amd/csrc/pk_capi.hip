@@ -33,8 +33,8 @@ int group_width(int S) { return S <= 8 ? 8 : S <= 16 ? 16 : S <= 32 ? 32 : S <= 
 int check_model(pk_ctx* c, int model, int n_sites) {
   if (model < 0 || model > 2) return fail(c, PK_ERR_ARG, "model must be 0 (dist), 1 (succ) or 2 (rand)");
   if (n_sites < 1) return fail(c, PK_ERR_ARG, "n_sites must be >= 1");
-  if (model == PK_MODEL_RAND && n_sites > 5) return fail(c, PK_ERR_UNSUPPORTED, "randmod: n_sites <= 5 (S = 2^n + 1 <= 64 lanes)");
-  if (pk::n_states(model, n_sites) > 64) return fail(c, PK_ERR_UNSUPPORTED, "S = n_sites + 2 must be <= 64 (one lane per state)");
+  if (model == PK_MODEL_RAND && n_sites > 6) return fail(c, PK_ERR_UNSUPPORTED, "randmod: n_sites <= 6 (2^n bit-mask rows <= 64 lanes)");
+  if (model != PK_MODEL_RAND && pk::n_states(model, n_sites) > 64) return fail(c, PK_ERR_UNSUPPORTED, "S = n_sites + 2 must be <= 64 (one lane per state)");
   return PK_OK;
 }
 
@@ -156,7 +156,10 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   a.F = pk_protein_flat_len(model, n_sites, T); a.n_obs = n_sites; a.y0_batched = y0_is_batched ? 1 : 0; a.metric_id = metric_id;
   a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.rk4_h = o.rk4_h; a.max_steps = o.max_steps; a.clip = o.clip_nonneg; a.normalize = o.normalize; a.stage_form = o.stage_form;
 
-  const int G = group_width(a.S);
+  const bool rand_fast = model == PK_MODEL_RAND && (o.method == PK_METHOD_RODAS4 || o.method == PK_METHOD_LRP8) && (o.linsolve == PK_LINSOLVE_AUTO || a.S > 64) && !o.stage_form;
+  if (a.S > 64 && !rand_fast)       // n = 6: the in-register inverse of pk_rand_fast.hpp is the only solver (every `linsolve` value selects it)
+    return fail(c, PK_ERR_UNSUPPORTED, "randmod n_sites = 6 (S = 65): only method RODAS4 / LRP8 in resolvent form (the generic kernels hold one state per lane)");
+  const int G = a.S > 64 ? 64 : group_width(a.S);
   const long long rpb = 256 / G;
   const long long nblk = (B + rpb - 1) / rpb;
   if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
@@ -165,7 +168,7 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   dim3 grid((unsigned)nblk);
   if (model == PK_MODEL_DIST && (o.method == PK_METHOD_RODAS4 || o.method == PK_METHOD_LRP8) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
     pk::launch_dist_fast(a, o.method, c->stream);                      // throughput layout: 4-16 lanes per replica, shadowed R / P rows
-  else if (model == PK_MODEL_RAND && (o.method == PK_METHOD_RODAS4 || o.method == PK_METHOD_LRP8) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
+  else if (rand_fast)
     pk::launch_rand_fast(a, o.method, c->stream);                  // 2^n lanes per replica, shadowed mRNA row
   else
     kSolve[model][gidx(G)](a, o.method, structured, grid, c->stream);
@@ -180,12 +183,13 @@ int pk_rhs_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const dou
   if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
   if (B == 0) return PK_OK;
   if (!theta || !y || !dydt) return fail(c, PK_ERR_ARG, "null pointer");
-  const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), G = group_width(S);
-  const long long rpb = 256 / G, nblk = (B + rpb - 1) / rpb;
+  const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), G = S > 64 ? 1 : group_width(S);
+  const long long rpb = 256 / G, nblk = (S > 64 ? (B * S + 255) / 256 : (B + rpb - 1) / rpb);
   if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
   PK_HIP(c, hipSetDevice(c->device));
   dim3 grid((unsigned)nblk);
-  kRhs[model][gidx(G)](theta, y, dydt, (long long)B, n_sites, S, P, grid, c->stream);
+  if (S > 64) pk::launch_rand_rhs_wide(theta, y, dydt, (long long)B, n_sites, S, P, c->stream);
+  else kRhs[model][gidx(G)](theta, y, dydt, (long long)B, n_sites, S, P, grid, c->stream);
   PK_HIP(c, hipGetLastError());
   return PK_OK;
 }
@@ -197,12 +201,13 @@ int pk_jacobian_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, cons
   if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
   if (B == 0) return PK_OK;
   if (!theta || !J) return fail(c, PK_ERR_ARG, "null pointer");
-  const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), G = group_width(S);
-  const long long rpb = 256 / G, nblk = (B + rpb - 1) / rpb;
+  const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), G = S > 64 ? 1 : group_width(S);
+  const long long rpb = 256 / G, nblk = (S > 64 ? (B * S + 255) / 256 : (B + rpb - 1) / rpb);
   if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
   PK_HIP(c, hipSetDevice(c->device));
   dim3 grid((unsigned)nblk);
-  kJac[model][gidx(G)](theta, J, (long long)B, n_sites, S, P, grid, c->stream);
+  if (S > 64) pk::launch_rand_jac_wide(theta, J, (long long)B, n_sites, S, P, c->stream);
+  else kJac[model][gidx(G)](theta, J, (long long)B, n_sites, S, P, grid, c->stream);
   PK_HIP(c, hipGetLastError());
   return PK_OK;
 }

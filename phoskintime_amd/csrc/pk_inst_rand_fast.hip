@@ -21,6 +21,7 @@ void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {
     case 2: launch_nb<2>(a, method, st); break;
     case 3: launch_nb<3>(a, method, st); break;
     case 4: launch_nb<4>(a, method, st); break;
+    case 6: launch_nb<6>(a, method, st); break;            // 64 masks, one wave per replica, v_readlane broadcasts
     default: {
       // n = 5: two rows per lane in 16-lane groups (DPP broadcasts); PK_RAND5_G32=1 selects the one-row-per-lane 32-lane kernel (A/B)
       static const bool g32 = getenv("PK_RAND5_G32") && atoi(getenv("PK_RAND5_G32")) != 0;
@@ -30,6 +31,56 @@ void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {
       else                          hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
     } break;
   }
+}
+
+// ---- n = 6 (S = 65 states > one wave): right-hand side and Jacobian with one thread per (replica, row); y is read from memory.
+__global__ void rand_rhs_wide_kernel(const double* __restrict__ theta, const double* __restrict__ y, double* __restrict__ dydt,
+                                     const long long B, const int n, const int S, const int P) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * S) return;
+  const long long rep = gid / S;
+  const int row = (int)(gid - rep * S);
+  const RowCoef c = load_row<M_RAND>(theta + rep * P, n, S, row);
+  const double* yr = y + rep * S;
+  double f = __builtin_fma(c.dg, yr[row], c.bias);
+  if (row >= 1) {
+    const int m = row - 1;
+    f = __builtin_fma(c.c2, yr[0], f);
+    for (int j = 0; j < n; ++j) {
+      const int bit = 1 << j;
+      f = __builtin_fma((m & bit) ? c.c1 : 1.0, yr[(m ^ bit) + 1], f);
+    }
+  }
+  dydt[gid] = f;
+}
+
+__global__ void rand_jac_wide_kernel(const double* __restrict__ theta, double* __restrict__ J, const long long B, const int n,
+                                     const int S, const int P) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * S) return;
+  const long long rep = gid / S;
+  const int row = (int)(gid - rep * S);
+  const RowCoef c = load_row<M_RAND>(theta + rep * P, n, S, row);
+  double* Jr = J + gid * S;
+  for (int j = 0; j < S; ++j) Jr[j] = 0.0;
+  Jr[row] = c.dg;
+  if (row >= 1) {
+    const int m = row - 1;
+    if (row == 1) Jr[0] = c.c2;
+    for (int j = 0; j < n; ++j) {
+      const int bit = 1 << j;
+      Jr[(m ^ bit) + 1] = (m & bit) ? c.c1 : 1.0;
+    }
+  }
+}
+
+void launch_rand_rhs_wide(const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t st) {
+  const long long nblk = (B * S + 255) / 256;
+  hipLaunchKernelGGL(rand_rhs_wide_kernel, dim3((unsigned)nblk), dim3(256), 0, st, theta, y, dydt, B, n, S, P);
+}
+void launch_rand_jac_wide(const double* theta, double* J, long long B, int n, int S, int P, hipStream_t st) {
+  const long long nblk = (B * S + 255) / 256;
+  hipLaunchKernelGGL(rand_jac_wide_kernel, dim3((unsigned)nblk), dim3(256), 0, st, theta, J, B, n, S, P);
 }
 
 }  // namespace pk

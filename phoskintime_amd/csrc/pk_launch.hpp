@@ -22,5 +22,7 @@ PK_DECL(2, 8) PK_DECL(2, 16) PK_DECL(2, 32) PK_DECL(2, 64)
 void launch_dist_fast(const SolveArgs&, int method, hipStream_t);
 // random-model throughput kernel (pk_rand_fast.hpp): RODAS4 / LRP8, in-register Gauss-Jordan on the 2^n coupled rows
 void launch_rand_fast(const SolveArgs&, int method, hipStream_t);
+void launch_rand_rhs_wide(const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t);
+void launch_rand_jac_wide(const double* theta, double* J, long long B, int n, int S, int P, hipStream_t);
 
 }  // namespace pk

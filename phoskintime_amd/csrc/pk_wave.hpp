@@ -122,14 +122,22 @@ __device__ __forceinline__ double partner(double v, int lane) {
   }
 }
 
-// value of lane (lane ^ MASK), MASK < 32: exact XOR partner (hypercube neighbours of the randmod bit-mask states)
+// value of lane (lane ^ MASK): exact XOR partner (hypercube neighbours of the randmod bit-mask states).
+// MASK 1, 2, 3: quad_perm; 4 and 8: two DPP mirrors composed (xor 7 . xor 3, xor 15 . xor 7) -- VALU only; 16: ds_swizzle; 32: ds_bpermute
 template <int MASK>
 __device__ __forceinline__ double xor_partner(double v) {
-  static_assert(MASK > 0 && MASK < 32, "xor mask");
+  static_assert(MASK > 0 && MASK < 64, "xor mask");
   if constexpr (MASK == 1) return dpp_mov<0xB1>(v);
   else if constexpr (MASK == 2) return dpp_mov<0x4E>(v);
   else if constexpr (MASK == 3) return dpp_mov<0x1B>(v);     // quad_perm [3,2,1,0]
-  else {
+  else if constexpr (MASK == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));     // row_half_mirror (i -> 7 - i) then quad reverse (i -> i ^ 3)
+  else if constexpr (MASK == 8) return dpp_mov<0x141>(dpp_mov<0x140>(v));    // row_mirror (i -> 15 - i) then row_half_mirror
+  else if constexpr (MASK == 32) {
+    const int addr = (lane_id() ^ 32) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  } else {
     constexpr int pat = 0x1f | (MASK << 10);
     const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);

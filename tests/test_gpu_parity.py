@@ -140,7 +140,9 @@ def test_argument_errors(eng):
     with pytest.raises(ValueError):
         eng.solve_ode_batch(0, np.ones((2, 12)), np.ones(5), 4, pm.TIME_POINTS)          # wrong S
     with pytest.raises(PhoskinError):
-        eng.solve_ode_batch(2, np.ones((1, 4 + 6 + 63)), np.ones(65), 6, pm.TIME_POINTS)  # randmod n = 6: S = 65 > 64 lanes
+        eng.solve_ode_batch(2, np.ones((1, 4 + 7 + 127)), np.ones(129), 7, pm.TIME_POINTS)  # randmod n = 7: 128 bit-mask rows > 64 lanes
+    with pytest.raises(PhoskinError):
+        eng.solve_ode_batch(2, np.ones((1, 4 + 6 + 63)), np.ones(65), 6, pm.TIME_POINTS, method="bdf2")  # n = 6 only has the resolvent kernels
     with pytest.raises(PhoskinError):
         eng.solve_ode_batch(0, np.ones((1, 12)), np.ones(6), 4, pm.TIME_POINTS, rtol=-1.0)
 

@@ -15,7 +15,7 @@ def _load(f):
 
 def test_golden_inventory(golden_files):
     names = {f.name for f in golden_files}
-    for model, ns in (("distmod", (1, 2, 4, 8, 30)), ("succmod", (1, 2, 4, 8, 14)), ("randmod", (1, 2, 3, 4, 5))):
+    for model, ns in (("distmod", (1, 2, 4, 8, 30)), ("succmod", (1, 2, 4, 8, 14)), ("randmod", (1, 2, 3, 4, 5, 6))):
         for n in ns:
             assert f"protein_{model}_n{n}_bounds.npz" in names
             assert f"protein_{model}_n{n}_real.npz" in names

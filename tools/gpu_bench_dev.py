@@ -39,6 +39,9 @@ if __name__ == '__main__':
             for nb in (1, 2, 3, 4, 5):
                 run(2, nb, 65536, meth, 'auto')
             run(0, 4, 65536, meth, 'auto')
+    if which in ('all', 'rand'):
+        for nb in (4, 5, 6):
+            run(2, nb, 65536 if nb < 6 else 16384, 'lrp8', 'auto')
     if which in ('all', 'c3'):
         run(0, 30, 65536, 'rodas4', 'structured', 0.05, 2.0)
         run(0, 30, 65536, 'bdf2', 'structured')

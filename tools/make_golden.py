@@ -112,7 +112,11 @@ def main():
         np.savez_compressed(OUT / f"protein_{name}_n{n}_{tag}.npz", **d)
         print("wrote", name, n, tag, "K =", K, flush=True)
 
-    plan = {"distmod": [1, 2, 4, 8, 30], "succmod": [1, 2, 4, 8, 14], "randmod": [1, 2, 3, 4, 5]}
+    plan = {"distmod": [1, 2, 4, 8, 30], "succmod": [1, 2, 4, 8, 14], "randmod": [1, 2, 3, 4, 5, 6]}
+    only = None
+    if len(sys.argv) == 3:                      # `make_golden.py randmod 6`: (re)generate the two case sets of one model / size only
+        only = (sys.argv[1], int(sys.argv[2]))
+        plan = {only[0]: [only[1]]}
     for name, ns in plan.items():
         for n in ns:
             P, S = n_params(name, n), n_states(name, n)
@@ -128,6 +132,8 @@ def main():
             # (ii) "realistic" U(0.05, 2)
             th_r = [rng.uniform(0.05, 2.0, P) for _ in range(K)]
             make_case_set(name, n, th_r, [np.ones(S) for _ in range(K)], "real")
+        if only:
+            continue
         # (iii) edge cases at n = 4: knock-outs (knockout/helper.py:20-36), params on the bounds 0 and 20
         n = 4; P, S = n_params(name, n), n_states(name, n)
         rng = np.random.default_rng(77)
@@ -145,7 +151,7 @@ def main():
         make_case_set(name, n, edge, [np.ones(S) for _ in edge], "edge")
 
     # (iv) bench-shaped subsamples: first 64 replicas of the C2 / C3 synthetic batches
-    for name, n, cfg_idx, lo_hi, tag in (("succmod", 14, 1, (0.0, 20.0), "c2bounds"), ("succmod", 14, 1, (0.05, 2.0), "c2benign"),
+    for name, n, cfg_idx, lo_hi, tag in () if only else (("succmod", 14, 1, (0.0, 20.0), "c2bounds"), ("succmod", 14, 1, (0.05, 2.0), "c2benign"),
                                          ("distmod", 30, 2, (0.0, 20.0), "c3bounds"), ("distmod", 30, 2, (0.05, 2.0), "c3benign")):
         P, S = n_params(name, n), n_states(name, n)
         seed = 20260515 + cfg_idx + (1000 if "benign" in tag else 0)
