@@ -36,8 +36,10 @@ enum {
   PK_METHOD_RODAS4 = 0, /* 6-stage L-stable Rosenbrock 4(3) (Hairer-Wanner RODAS), analytic Jacobian, 1 factorisation / step */
   PK_METHOD_BDF2   = 1, /* variable-step BDF2 (BDF1 start), analytic Jacobian, 1 factorisation / step (BASELINE config 3) */
   PK_METHOD_RK4    = 2, /* classical explicit RK4, fixed step h <= rk4_h (BASELINE config 2); stability-bound when stiff */
-  PK_METHOD_LRP8   = 3  /* L-stable restricted-Pade one-step method for affine systems: 8 resolvent solves, 1 rhs and
+  PK_METHOD_LRP8   = 3, /* L-stable restricted-Pade one-step method for affine systems: 8 resolvent solves, 1 rhs and
                            1 factorisation per step, order 7 with an embedded order-6 estimate */
+  PK_METHOD_DP5    = 4  /* pk_network_simulate_batch only: the reference's opt-in explicit integrator, step for step -- Dormand-Prince
+                           5(4), PI controller, dt in [1e-6, 1], bucket-edge landing, Hermite output (global_model/solvers.py:293-758) */
 };
 
 /* Linear solver for the implicit stage equations (g I - J) x = r. */
@@ -168,7 +170,9 @@ int pk_network_jacobian_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int 
 /* Replaces global_model.simulate.simulate_odeint(sys, t_eval, rtol, atol, mxstep) -> Y[T,S] (simulate.py:34-80) for B candidates
  * of one network: x [B,n_var] and y0 ([S] or [B,S]) are device pointers, t is a HOST pointer to T strictly increasing times
  * (t[0] = initial time), Y [B,T,S] device.  Integrator: ROS34PW2 Rosenbrock-W with the per-protein diagonal blocks of the analytic
- * Jacobian; opts->rtol / atol / h0 / max_steps are honoured, method / linsolve are ignored.  Topologies 0, 1, 4. */
+ * Jacobian for every opts->method except PK_METHOD_DP5, which selects the reference's explicit RK45 (jacspeedup.solve_custom,
+ * jacspeedup.py:31-64; h0 = dt_init, 0 -> 0.05; max_steps <= 0 -> 2 000 000).  opts->rtol / atol / h0 / max_steps are honoured.
+ * Topologies 0, 1, 4; the combinatorial one (2) with <= 3 sites per protein under the W-method and with any block size under DP5. */
 int pk_network_simulate_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
                               const double* t_host, int T, const pk_solver_opts* opts, double* Y, int32_t* status, int32_t* n_steps);
 /* global_model.params.unpack_params (softplus of the raw decision vectors): x_raw [B,n_var] -> x_phys [B,n_var]. */

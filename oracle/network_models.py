@@ -260,6 +260,110 @@ def simulate_odeint(net: Network, p: Params, t_eval, rtol, atol, mxstep, y0=None
     return np.ascontiguousarray(odeint(f, y0, np.asarray(t_eval, float), rtol=rtol, atol=atol, mxstep=mxstep, **kw))
 
 
+# Dormand-Prince 5(4) tableau as used by the reference (solvers.py:338-365); rows of A for stages 2..6, 5th-order weights B (= row 7,
+# FSAL), error weights E (5th minus 4th order)
+DP_A = (
+    (1 / 5,),
+    (3 / 40, 9 / 40),
+    (44 / 45, -56 / 15, 32 / 9),
+    (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+    (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+)
+DP_B = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)
+DP_E = (71 / 57600, 0.0, -71 / 16695, 71 / 1920, -17253 / 339200, 22 / 525, -1 / 40)
+
+
+def simulate_rk45(net: Network, p: Params, t_eval, rtol=1e-5, atol=1e-7, y0=None, dt_init=0.05, dt_min=1e-6, dt_max=1.0, safety=0.9,
+                  max_steps=2_000_000, return_steps=False):
+    """The reference's opt-in explicit integrator (solvers.py:293-577 models 0/1/4, :580-758 model 2; reached through
+    jacspeedup.solve_custom, jacspeedup.py:31-64), restated step for step:
+      * the kinase bucket `jb` is carried by the integrator (advanced when tcur >= grid[jb + 1]); every stage of a step uses it;
+      * a step is cut to land exactly on the next bucket edge and on t_final, and floored at dt_min;
+      * error = max_i |dt * sum_j E_j k_j| / max(atol + rtol * max(|y_i|, |y_new_i|), 1e-12);
+      * accepted: outputs inside (tcur, t_next] by cubic Hermite on (y, k1) / (y_new, k7); FSAL unless the step ended on a bucket edge;
+        PI controller fac = safety * err^-(0.2 - 0.04) * err_prev^0.04 in [0.2, 5] (5 if err < 1e-12), dt <= dt_max, err_prev >= 1e-4;
+      * rejected: fac = max(0.1, safety * err^-0.2), dt = max(dt_use * fac, dt_min), err_prev = 1.
+    """
+    t_eval = np.asarray(t_eval, float)
+    grid = net.kin_grid
+    y = (default_y0(net) if y0 is None else np.asarray(y0, float)).copy()
+    T = t_eval.size
+    Y = np.empty((T, y.size))
+    Y[0] = y
+    f = lambda yy, jb: rhs(net, p, yy, grid[jb])          # any t inside bucket jb gives that bucket's right-hand side
+    jb = 0
+    tcur, t_final = t_eval[0], t_eval[-1]
+    while jb + 1 < grid.size and tcur >= grid[jb + 1]:
+        jb += 1
+    nxt = 1
+    beta = 0.04
+    alpha = 0.2 - beta
+    err_prev = 1.0
+    k = [None] * 7
+    k[0] = f(y, jb)
+    dt = dt_init
+    steps = acc = 0
+    hit = False
+    while tcur < t_final and nxt < T:
+        steps += 1
+        if steps > max_steps:
+            raise RuntimeError("Max steps exceeded")
+        while jb + 1 < grid.size and tcur >= grid[jb + 1]:
+            jb += 1
+            hit = True
+        if hit:
+            k[0] = f(y, jb)
+            hit = False
+            err_prev = 1.0
+        dt_use = dt
+        dist = 1e9
+        if jb + 1 < grid.size:
+            dist = grid[jb + 1] - tcur
+            if dist > 1e-15 and dt_use > dist:
+                dt_use = dist
+        dt_use = min(dt_use, t_final - tcur)
+        dt_use = max(dt_use, dt_min)
+        for s in range(1, 6):
+            inc = DP_A[s - 1][0] * k[0]
+            for j in range(1, s):
+                inc = inc + DP_A[s - 1][j] * k[j]
+            k[s] = f(y + dt_use * inc, jb)
+        y_new = y + dt_use * (DP_B[0] * k[0] + DP_B[2] * k[2] + DP_B[3] * k[3] + DP_B[4] * k[4] + DP_B[5] * k[5])
+        k[6] = f(y_new, jb)
+        diff = dt_use * (DP_E[0] * k[0] + DP_E[2] * k[2] + DP_E[3] * k[3] + DP_E[4] * k[4] + DP_E[5] * k[5] + DP_E[6] * k[6])
+        sc = np.maximum(atol + rtol * np.maximum(np.abs(y), np.abs(y_new)), 1e-12)
+        err = float(np.max(np.abs(diff) / sc))
+        if err <= 1.0:
+            acc += 1
+            t_next = tcur + dt_use
+            while nxt < T and t_eval[nxt] <= t_next:
+                te = t_eval[nxt]
+                if te >= tcur:
+                    h = t_next - tcur
+                    if h < 1e-16:
+                        Y[nxt] = y_new
+                    else:
+                        tau = (te - tcur) / h
+                        t2, t3 = tau * tau, tau * tau * tau
+                        Y[nxt] = ((2 * t3 - 3 * t2 + 1) * y + (t3 - 2 * t2 + tau) * h * k[0] + (-2 * t3 + 3 * t2) * y_new + (t3 - t2) * h * k[6])
+                nxt += 1
+            y = y_new
+            tcur = t_next
+            if abs(dt_use - dist) < 1e-14:
+                hit = True
+            else:
+                k[0] = k[6]
+            fac = 5.0 if err < 1e-12 else safety * err ** (-alpha) * err_prev ** beta
+            fac = min(5.0, max(0.2, fac))
+            dt = min(dt * fac, dt_max)
+            err_prev = max(err, 1e-4)
+        else:
+            fac = max(0.1, safety * err ** (-0.2))
+            dt = max(dt_use * fac, dt_min)
+            err_prev = 1.0
+    return (Y, acc, steps - acc) if return_steps else Y
+
+
 # ------------------------------------------------------------------------------------------------ loss / objective
 EPS_LOSS = 1e-9   # lossfn.py:24
 

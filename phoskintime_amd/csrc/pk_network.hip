@@ -8,6 +8,7 @@
 #include "pk_network_solve.hpp"
 #include "pk_network_solve_reg.hpp"
 #include "pk_network_solve_reg2.hpp"
+#include "pk_network_rk45.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -218,15 +219,17 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   if (B == 0) return PK_OK;
   if (!x || !y0 || !Y) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
   if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
-  if (n->d.model == 2 && (n->max_sites > 3 || n->d.N > 256))
+  const bool dp5 = opts_in && opts_in->method == PK_METHOD_DP5;
+  if (!dp5 && n->d.model == 2 && (n->max_sites > 3 || n->d.N > 256))
     return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate, combinatorial topology: <= 3 sites per protein (8 phospho states per thread) and N <= 256");
-  if (n->d.model != 2 && n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
+  if (!dp5 && n->d.model != 2 && n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
   if (n->d.S > 1024 || n->d.N > 512) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate: S <= 1024 states and N <= 512 proteins per network");
   for (int k = 1; k < T; ++k) if (!(t_host[k] > t_host[k - 1])) return pk_ctx_fail(c, PK_ERR_ARG, "t must be strictly increasing");
   pk_solver_opts o;
   if (opts_in) o = *opts_in; else pk_default_opts(&o);
   if (!(o.rtol > 0.0 && o.atol >= 0.0)) return pk_ctx_fail(c, PK_ERR_ARG, "rtol must be > 0 and atol >= 0");
-  if (o.max_steps <= 0) o.max_steps = 1000000;
+  if (o.max_steps <= 0) o.max_steps = dp5 ? 2000000 : 1000000;      // solvers.py:294 max_steps = 2_000_000
+  if (dp5 && pk::net_rk45_lds_bytes(n->d) > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
   // landing points: every output time after t[0] plus every bucket edge strictly inside (t[0], t[T-1])
   std::vector<std::pair<double, int>> st;
   for (int k = 1; k < T; ++k) st.push_back({t_host[k], k});
@@ -238,6 +241,10 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
     }
   }
   std::sort(st.begin(), st.end());
+  if (dp5) {                                        // the explicit integrator interpolates its outputs: it only needs the T output times
+    st.clear();
+    for (int k = 0; k < T; ++k) st.push_back({t_host[k], k});
+  }
   pk::NetSolveArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.x_is_raw = x_is_raw; a.y0 = y0; a.y0_batched = y0_is_batched ? 1 : 0; a.t0 = t_host[0]; a.T = T; a.Y = Y;
@@ -264,6 +271,18 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
         hipMemcpy(n->stop_out_dev, so.data(), so.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
       return pk_ctx_fail(c, PK_ERR_HIP, "hipMemcpy");
     a.stops_p = n->stops_dev; a.stop_out_p = n->stop_out_dev;
+  }
+  if (dp5) {
+    const size_t lb = pk::net_rk45_lds_bytes(n->d);
+#define PK_RK_LAUNCH(M)                                                                                                              \
+    do {                                                                                                                               \
+      if (lb > 48 * 1024) (void)hipFuncSetAttribute((const void*)pk::net_rk45_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+      hipLaunchKernelGGL(pk::net_rk45_kernel<M>, dim3((unsigned)B), dim3(256), lb, stream, n->d, a);                                   \
+    } while (0)
+    if (n->d.model == 0) PK_RK_LAUNCH(0); else if (n->d.model == 1) PK_RK_LAUNCH(1); else if (n->d.model == 2) PK_RK_LAUNCH(2); else PK_RK_LAUNCH(4);
+#undef PK_RK_LAUNCH
+    hipError_t er = hipGetLastError();
+    return er == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(er));
   }
   // Register-resident kernel (one thread per protein) when every block fits its per-thread arrays; opts->linsolve ==
   // PK_LINSOLVE_STRUCTURED forces the LDS kernel (kept as the general fallback and as the A/B reference).

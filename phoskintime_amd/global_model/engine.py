@@ -127,10 +127,13 @@ class NetworkEngine:
         return out
 
     def simulate_batch(self, x, t_eval, y0=None, raw: bool = False, rtol: float = 1e-7, atol: float = 1e-9, max_steps: int = 1000000,
-                       h0: float = 0.0, kernel: str = "auto"):
+                       h0: float = 0.0, kernel: str = "auto", method: str = "rosw"):
         """Y [B, T, S] for B candidates: reference ``simulate_odeint(sys, t_eval, rtol, atol, mxstep)`` (simulate.py:34-80) batched.
         Returns (Y, status [B], n_steps [B, 2]) as GPU tensors; flagged candidates have NaN rows (callers test np.isfinite,
-        optproblem.py:125-133)."""
+        optproblem.py:125-133).  method = "rosw": the Rosenbrock-W production integrator; "dp5": the reference's explicit RK45
+        (solvers.py:293-758) step for step."""
+        if method not in ("rosw", "dp5"):
+            raise ValueError("method must be 'rosw' or 'dp5'")
         dev = torch.device("cuda", self.ctx.device)
         xd = _dev_f64(x, dev)
         if xd.dim() == 1:
@@ -151,7 +154,8 @@ class NetworkEngine:
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
         nsteps = torch.zeros((B, 2), dtype=torch.int32, device=dev)
         # kernel = "auto": register-resident one-thread-per-protein kernel when eligible; "lds": the general LDS kernel
-        opts = _capi.default_opts(rtol=rtol, atol=atol, max_steps=max_steps, h0=h0, linsolve=("structured" if kernel == "lds" else "auto"))
+        opts = _capi.default_opts(rtol=rtol, atol=atol, max_steps=max_steps, h0=h0, linsolve=("structured" if kernel == "lds" else "auto"),
+                                  method=("dp5" if method == "dp5" else None))
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         self.ctx.check(self.ctx.lib.pk_network_simulate_batch(self.ctx.handle, self._h, B, _ptr(xd), int(raw), _ptr(yd), yb, th.ctypes.data, T,
                                                              C.byref(opts), _ptr(Y), _ptr(status), _ptr(nsteps)))

@@ -57,10 +57,16 @@ def fd_jacobian_odeint(y, t, *args):
 
 
 def solve_custom(sys, y0, t_eval, rtol, atol):
-    """Y [T, S] for the system's current parameters from an explicit y0 (reference: adaptive RK45 dispatch, jacspeedup.py:31-64)."""
+    """Y [T, S] for the system's current parameters from an explicit y0: the reference's adaptive RK45 (jacspeedup.py:31-64 ->
+    solvers.adaptive_rk45_model01 / _model2), same steps on the GPU (PK_METHOD_DP5).  Raises RuntimeError when max_steps (2 000 000) is
+    exceeded, as solvers.py:379 does."""
     from .simulate import engine_for, candidate_of
+    from .._capi import ST_MAXSTEPS
     eng = engine_for(sys)
-    Y, _, _ = eng.simulate_batch(candidate_of(sys, eng)[None, :], np.asarray(t_eval, float), y0=np.asarray(y0, float), rtol=rtol, atol=atol)
+    Y, status, _ = eng.simulate_batch(candidate_of(sys, eng)[None, :], np.asarray(t_eval, float), y0=np.asarray(y0, float), rtol=rtol, atol=atol,
+                                      max_steps=2_000_000, method="dp5")
+    if int(status[0]) & ST_MAXSTEPS:
+        raise RuntimeError("Max steps exceeded")
     return np.ascontiguousarray(Y[0].cpu().numpy())
 
 

@@ -6,10 +6,10 @@ from __future__ import annotations
 import numpy as np
 
 
-def make_network(N: int = 100, total_sites: int = 300, n_K: int = 40, n_tf_edges: int = 250, model: int = 0, seed: int = 20260519):
+def make_network(N: int = 100, total_sites: int = 300, n_K: int = 40, n_tf_edges: int = 250, model: int = 0, seed: int = 20260519, max_sites: int | None = None):
     rng = np.random.default_rng(seed)
     # sites per protein: >= 0, sum = total_sites, <= 6 (model 2: <= 3)
-    cap = 3 if model == 2 else 6
+    cap = max_sites if max_sites is not None else (3 if model == 2 else 6)
     n_sites = np.zeros(N, dtype=np.int32)
     while n_sites.sum() < total_sites:
         i = int(rng.integers(0, N))

@@ -61,3 +61,17 @@ def test_loss_function_matches_reference_all_modes(m):
             got = np.array(nm.loss_function(m, g["Y"][k], ld, mode))
             np.testing.assert_allclose(got, g["loss_sums"][mode, k], rtol=1e-13, atol=0, equal_nan=True)
     assert np.isnan(g["loss_sums"][2]).any()      # LOSS_MODE 2 takes log(diff + eps) of negative residuals in the reference itself
+
+
+@pytest.mark.parametrize("m", [0, 1, 2, 4])
+def test_oracle_rk45_restatement_reproduces_the_reference_integrator(m):
+    """oracle.simulate_rk45 (restating solvers.py:293-758) against the reference's own RK45 outputs stored in the fixtures."""
+    g = np.load(GOLD[0].parent / f"network_m{m}_small.npz")
+    net = nm.Network.from_npz(g)
+    for k in range(2):
+        Y = nm.simulate_rk45(net, nm.Params.from_npz(g, k), g["t_eval"], 1e-5, 1e-7, y0=g["y0"])
+        np.testing.assert_allclose(Y, g["Y_rk45"][k], rtol=1e-13, atol=1e-15)
+    Y = nm.simulate_rk45(net, nm.Params.from_npz(g, 0), g["t_eval"], 1e-9, 1e-11, y0=g["y0"])
+    np.testing.assert_allclose(Y, g["Y_rk45_tight"][0], rtol=1e-13, atol=1e-15)
+    # the explicit method at its default tolerance is ~1e-5 from the truth; at 1e-9 it agrees with LSODA at 1e-12
+    assert np.abs(g["Y_rk45_tight"][0] - g["Y_tight"][0]).max() < 1e-7

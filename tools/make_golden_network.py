@@ -114,6 +114,7 @@ def main(model_name):
         rhs_y0 = np.empty((K, t_probe.size, S)); rhs_rand = np.empty((K, t_probe.size, S))
         fdjac = np.empty((2, S, S)); Y8 = np.empty((K, t_eval.size, S)); Ytight = np.empty((2, t_eval.size, S))
         Scache = None
+        Yrk = np.empty((2, t_eval.size, S)); Yrk_tight = np.empty((1, t_eval.size, S))
         for k, ps in enumerate(psets):
             sysm.update(**ps)
             if MODEL == 2:
@@ -130,6 +131,11 @@ def main(model_name):
             Y8[k] = sim.simulate_odeint(sysm, t_eval, 1e-8, 1e-8, 200000)
             if k < 2:
                 Ytight[k] = sim.simulate_odeint(sysm, t_eval, 1e-12, 1e-12, 500000)
+            # the reference's opt-in explicit integrator (solvers.py:293-758 through jacspeedup.solve_custom, jacspeedup.py:31-64)
+            if k < 2:
+                Yrk[k] = js.solve_custom(sysm, y0.copy(), t_eval, 1e-5, 1e-7)          # simulate.py defaults for the custom solver
+            if k < 1:
+                Yrk_tight[k] = js.solve_custom(sysm, y0.copy(), t_eval, 1e-9, 1e-11)
             print(model_name, tag, "param set", k, "done", flush=True)
         driver_map = np.asarray(sysm.odeint_args(sysm.S_cache)[-3] if MODEL == 2 else sysm.odeint_args()[-1], dtype=np.int32)
         d = dict(model=MODEL, N=idx.N, n_K=len(idx.kinases), total_sites=idx.total_sites, S=S,
@@ -138,7 +144,7 @@ def main(model_name):
                  TF_indptr=sysm.TF_indptr, TF_indices=sysm.TF_indices, TF_data=sysm.TF_data, tf_deg=sysm.tf_deg,
                  driver_map=driver_map, kin_grid=sysm.kin_grid, kin_Kmat=sysm.kin_Kmat,
                  t_eval=t_eval, t_probe=t_probe, y0=y0, y_rand=y_rand, rhs_y0=rhs_y0, rhs_rand=rhs_rand, fd_jac=fdjac, fd_jac_t=3.0,
-                 Y_lsoda8=Y8, Y_tight=Ytight,
+                 Y_lsoda8=Y8, Y_tight=Ytight, Y_rk45=Yrk, Y_rk45_tight=Yrk_tight,
                  c_k=np.stack([p["c_k"] for p in psets]), A_i=np.stack([p["A_i"] for p in psets]), B_i=np.stack([p["B_i"] for p in psets]),
                  C_i=np.stack([p["C_i"] for p in psets]), D_i=np.stack([p["D_i"] for p in psets]), Dp_i=np.stack([p["Dp_i"] for p in psets]),
                  E_i=np.stack([p["E_i"] for p in psets]), tf_scale=np.array([p["tf_scale"] for p in psets]))
