@@ -116,6 +116,12 @@ int pk_rhs_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
 int pk_jacobian_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
                               const double* theta, double* J);
 
+/* Steady state y* of dy/dt = J(theta) y + b(theta) = 0 for B parameter vectors: y_ss [B,S] (device), status [B] (or NULL;
+ * PK_ST_NONFINITE + a NaN row when J is singular, e.g. no degradation).  Generalises steady.initial_condition(num_psites)
+ * (steady/initdist.py:9-50, initsucc.py:9-55, initrand.py:9-77: SLSQP on the steady-state equations with every rate fixed to 1,
+ * called once per protein at paramest/core.py:83) to per-replica theta; S <= 64. */
+int pk_steady_state_protein_batch(pk_ctx*, int model, int n_sites, int64_t B, const double* theta, double* y_ss, int32_t* status);
+
 /* Replaces config.config.score_fit(params, target, prediction, alpha, beta, gamma, delta, mu) (config/config.py:176-226) for B
  * candidates: theta [B,P], target [N] (shared), pred [B,N] (e.g. the `flat` output) -> out [B].  weights = {alpha (rmse), beta (mae),
  * gamma (var), delta (mse), mu (l2)} as a HOST pointer, NULL = all 1 (config/constants.py:77-83). */

@@ -172,6 +172,28 @@ def lti_matrix(model: int, params, n_sites: int):
     return M, b
 
 
+def steady_state(model: int, params, n_sites: int):
+    """y* with M y* + b = 0.  steady/initdist.py:9-50, initsucc.py:9-55 and initrand.py:9-77 pose exactly these equations (every rate
+    fixed to 1) as an SLSQP feasibility problem; for the affine models the solution is this linear solve."""
+    M, b = lti_matrix(model, params, n_sites)
+    return np.linalg.solve(M, -b)
+
+
+def initial_condition(kind: str, n_sites: int):
+    """The list steady.<kind>.initial_condition(n) returns: unit rates; initsucc uses the DISTRIBUTIVE equations (initsucc.py:39-41);
+    initrand orders the phospho states by subset size then lexicographically (initrand.py:24-28) instead of by bit mask."""
+    from itertools import combinations
+    model = {"initdist": 0, "initsucc": 0, "initrand": 2}[kind]
+    y = steady_state(model, np.ones(n_params(model, n_sites)), n_sites)
+    if kind != "initrand":
+        return y
+    out = [y[0], y[1]]
+    for k in range(1, n_sites + 1):
+        for comb in combinations(range(1, n_sites + 1), k):
+            out.append(y[1 + sum(1 << (s - 1) for s in comb)])
+    return np.array(out)
+
+
 def jacobian_analytic(model: int, params, n_sites: int):
     """Closed-form Jacobian, written independently of `lti_matrix` (row-major J[i, j] = d f_i / d y_j)."""
     A, B, C, D, S, Dr = unpack_params(model, params, n_sites)

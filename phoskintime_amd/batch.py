@@ -170,6 +170,23 @@ def jacobian_batch(model, theta: ArrayLike, num_psites: int, device: Optional[in
     return out
 
 
+def steady_state_batch(model, theta: ArrayLike, num_psites: int, device: Optional[int] = None):
+    """Steady states y* [B, S] of dy/dt = J(theta) y + b(theta) for B parameter vectors, and status [B] (1 = singular J, NaN row).
+    ``steady.initial_condition(n)`` of the reference (steady/init*.py) is the special case theta = ones."""
+    ctx = get_context(device)
+    dev = torch.device("cuda", ctx.device)
+    mid, n = model_id(model), int(num_psites)
+    S, P = n_states(mid, n), n_params(mid, n)
+    th = _dev_f64(theta, dev).reshape(-1, P)
+    out = torch.empty((th.shape[0], S), dtype=torch.float64, device=dev)
+    status = torch.zeros((th.shape[0],), dtype=torch.int32, device=dev)
+    if th.shape[0]:
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ctx.check(ctx.lib.pk_steady_state_protein_batch(ctx.handle, mid, n, th.shape[0], _ptr(th), _ptr(out), _ptr(status)))
+        out._keepalive = (th,)  # type: ignore[attr-defined]
+    return out, status
+
+
 def score_fit_batch(theta: ArrayLike, target: ArrayLike, prediction: ArrayLike, alpha: float = 1.0, beta: float = 1.0, gamma: float = 1.0,
                     delta: float = 1.0, mu: float = 1.0, device: Optional[int] = None) -> torch.Tensor:
     """``config.config.score_fit`` (reference config/config.py:176-226) for B candidates: theta [B, P], target [N], prediction [B, N]."""

@@ -44,6 +44,7 @@ int gidx(int G) { return G == 8 ? 0 : G == 16 ? 1 : G == 32 ? 2 : 3; }
 const pk::SolveLauncher kSolve[3][4] = {PK_ROW(launch_solve_m, 0), PK_ROW(launch_solve_m, 1), PK_ROW(launch_solve_m, 2)};
 const pk::RhsLauncher kRhs[3][4] = {PK_ROW(launch_rhs_m, 0), PK_ROW(launch_rhs_m, 1), PK_ROW(launch_rhs_m, 2)};
 const pk::JacLauncher kJac[3][4] = {PK_ROW(launch_jac_m, 0), PK_ROW(launch_jac_m, 1), PK_ROW(launch_jac_m, 2)};
+const pk::SteadyLauncher kSteady[3][4] = {PK_ROW(launch_steady_m, 0), PK_ROW(launch_steady_m, 1), PK_ROW(launch_steady_m, 2)};
 #undef PK_ROW
 
 }  // namespace
@@ -208,6 +209,24 @@ int pk_jacobian_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, cons
   dim3 grid((unsigned)nblk);
   if (S > 64) pk::launch_rand_jac_wide(theta, J, (long long)B, n_sites, S, P, c->stream);
   else kJac[model][gidx(G)](theta, J, (long long)B, n_sites, S, P, grid, c->stream);
+  PK_HIP(c, hipGetLastError());
+  return PK_OK;
+}
+
+int pk_steady_state_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, double* y_ss, int32_t* status) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (B == 0) return PK_OK;
+  if (!theta || !y_ss) return fail(c, PK_ERR_ARG, "null pointer");
+  const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites);
+  if (S > 64) return fail(c, PK_ERR_UNSUPPORTED, "steady state: S <= 64 (randmod n_sites <= 5)");
+  const int G = group_width(S);
+  const long long rpb = 256 / G, nblk = (B + rpb - 1) / rpb;
+  if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+  PK_HIP(c, hipSetDevice(c->device));
+  kSteady[model][gidx(G)](theta, y_ss, status, (long long)B, n_sites, S, P, dim3((unsigned)nblk), c->stream);
   PK_HIP(c, hipGetLastError());
   return PK_OK;
 }

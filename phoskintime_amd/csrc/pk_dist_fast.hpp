@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256) void dist_fast_kernel(const SolveArgs A) {
     const double err = group_max(u6, y, yn);
     if (err != err || err > 1e300) {
       ++nrej; after_reject = true; h = 0.1 * hs;
-      const double bad = gmax<G>(((y.R - y.R != 0.0) || (y.P - y.P != 0.0) || (y.sg - y.sg != 0.0)) ? 1.0 : 0.0, lane);
-      if (bad != 0.0 || (cA - cA != 0.0) || (cB - cB != 0.0) || (cC - cC != 0.0) || (Dsum - Dsum != 0.0) || (Scw - Scw != 0.0)) {
+      const double bad = gmax<G>(((nonfinite(y.R)) || (nonfinite(y.P)) || (nonfinite(y.sg))) ? 1.0 : 0.0, lane);
+      if (bad != 0.0 || (nonfinite(cA)) || (nonfinite(cB)) || (nonfinite(cC)) || (nonfinite(Dsum)) || (nonfinite(Scw))) {
         status |= PK_ST_NONFINITE; fail_from(k); break;
       }
       continue;

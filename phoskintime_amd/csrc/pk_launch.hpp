@@ -8,11 +8,13 @@ namespace pk {
 using SolveLauncher = void (*)(const SolveArgs&, int method, bool structured, dim3 grid, hipStream_t);
 using RhsLauncher = void (*)(const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, dim3 grid, hipStream_t);
 using JacLauncher = void (*)(const double* theta, double* J, long long B, int n, int S, int P, dim3 grid, hipStream_t);
+using SteadyLauncher = void (*)(const double* theta, double* yss, int32_t* status, long long B, int n, int S, int P, dim3 grid, hipStream_t);
 
 #define PK_DECL(M, G)                                                                                     \
   void launch_solve_m##M##_g##G(const SolveArgs&, int, bool, dim3, hipStream_t);                           \
   void launch_rhs_m##M##_g##G(const double*, const double*, double*, long long, int, int, int, dim3, hipStream_t); \
-  void launch_jac_m##M##_g##G(const double*, double*, long long, int, int, int, dim3, hipStream_t);
+  void launch_jac_m##M##_g##G(const double*, double*, long long, int, int, int, dim3, hipStream_t);          \
+  void launch_steady_m##M##_g##G(const double*, double*, int32_t*, long long, int, int, int, dim3, hipStream_t);
 PK_DECL(0, 8) PK_DECL(0, 16) PK_DECL(0, 32) PK_DECL(0, 64)
 PK_DECL(1, 8) PK_DECL(1, 16) PK_DECL(1, 32) PK_DECL(1, 64)
 PK_DECL(2, 8) PK_DECL(2, 16) PK_DECL(2, 32) PK_DECL(2, 64)

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "pk_wave.hpp"
 
 namespace pk {
 

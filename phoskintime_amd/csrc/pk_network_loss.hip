@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void net_objective_kernel(const NetDev n, cons
   lp = block_sum(lp, red); lr = block_sum(lr, red); lph = block_sum(lph, red);
   // np.all(np.isfinite(Y)) over the whole trajectory (optproblem.py:130)
   double bad = 0.0;
-  for (size_t k = tid; k < (size_t)T * S; k += nt) { const double v = Yb[k]; if (v - v != 0.0) bad = 1.0; }
+  for (size_t k = tid; k < (size_t)T * S; k += nt) { const double v = Yb[k]; if (nonfinite(v)) bad = 1.0; }
   bad = block_sum(bad, red);
   if (status && status[b] != 0) bad = 1.0;
   double prior = 0.0;

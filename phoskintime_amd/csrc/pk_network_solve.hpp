@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256, 3) void net_solve_kernel(const NetDev n, const
       if (err != err || err > 1e300) {
         ++nrej; after_reject = true; h = 0.1 * hs;
         double bad = 0.0;
-        for (int k = tid; k < S; k += nt) if (y[k] - y[k] != 0.0) bad = 1.0;
-        for (int k = tid; k < n.n_var; k += nt) if (L.p[k] - L.p[k] != 0.0) bad = 1.0;
+        for (int k = tid; k < S; k += nt) if (nonfinite(y[k])) bad = 1.0;
+        for (int k = tid; k < n.n_var; k += nt) if (nonfinite(L.p[k])) bad = 1.0;
         if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
         continue;
       }

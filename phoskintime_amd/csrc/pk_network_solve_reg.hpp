@@ -241,10 +241,10 @@ __global__ __launch_bounds__(256, 2) void net_solve_reg_kernel(const NetDev n, c
       const double err = block_max(e, red);
       if (err != err || err > 1e300) {
         ++nrej; after_reject = true; h = 0.1 * hs;
-        double bad = (yR - yR != 0.0 || yP - yP != 0.0 || Ai - Ai != 0.0 || Bi - Bi != 0.0 || Ci - Ci != 0.0 || Di - Di != 0.0 || Ei - Ei != 0.0 ||
-                      ts - ts != 0.0) ? 1.0 : 0.0;
+        double bad = (nonfinite(yR) || nonfinite(yP) || nonfinite(Ai) || nonfinite(Bi) || nonfinite(Ci) || nonfinite(Di) || nonfinite(Ei) ||
+                      nonfinite(ts)) ? 1.0 : 0.0;
 #pragma unroll
-        for (int j = 0; j < MAXS; ++j) if (ys[j] - ys[j] != 0.0 || Dp[j] - Dp[j] != 0.0 || Sr[j] - Sr[j] != 0.0) bad = 1.0;
+        for (int j = 0; j < MAXS; ++j) if (nonfinite(ys[j]) || nonfinite(Dp[j]) || nonfinite(Sr[j])) bad = 1.0;
         if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
         continue;
       }

@@ -197,11 +197,11 @@ __global__ __launch_bounds__(256, 2) void net_solve_reg2_kernel(const NetDev n, 
       const double err = block_max(e, red);
       if (err != err || err > 1e300) {
         ++nrej; after_reject = true; h = 0.1 * hs;
-        double bad = (yR - yR != 0.0 || Ai - Ai != 0.0 || Bi - Bi != 0.0 || Ci - Ci != 0.0 || Di - Di != 0.0 || Ei - Ei != 0.0 || ts - ts != 0.0) ? 1.0 : 0.0;
+        double bad = (nonfinite(yR) || nonfinite(Ai) || nonfinite(Bi) || nonfinite(Ci) || nonfinite(Di) || nonfinite(Ei) || nonfinite(ts)) ? 1.0 : 0.0;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) if (ym[m] - ym[m] != 0.0) bad = 1.0;
+        for (int m = 0; m < NM; ++m) if (nonfinite(ym[m])) bad = 1.0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) if (Dp[j] - Dp[j] != 0.0 || Sr[j] - Sr[j] != 0.0) bad = 1.0;
+        for (int j = 0; j < NB; ++j) if (nonfinite(Dp[j]) || nonfinite(Sr[j])) bad = 1.0;
         if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
         continue;
       }

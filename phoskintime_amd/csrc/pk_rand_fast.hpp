@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void rand_fast_kernel(const SolveArgs A) {
     const double err = gmax<G>(mxn(ratio(e, y, yn), ratio(eR, yR, ynR)), lane);
     if (err != err || err > 1e300) {
       ++nrej; after_reject = true; h = 0.1 * hs;
-      const double bad = gmax<G>(((y - y != 0.0) || (yR - yR != 0.0) || (dgn - dgn != 0.0) || (cin - cin != 0.0) ||
-                                  (cA - cA != 0.0) || (cB - cB != 0.0) || (cC - cC != 0.0)) ? 1.0 : 0.0, lane);
+      const double bad = gmax<G>(((nonfinite(y)) || (nonfinite(yR)) || (nonfinite(dgn)) || (nonfinite(cin)) ||
+                                  (nonfinite(cA)) || (nonfinite(cB)) || (nonfinite(cC))) ? 1.0 : 0.0, lane);
       if (bad != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
       continue;
     }

@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void rand_fast2_kernel(const SolveArgs A) {
     const double err = gmax<G>(mxn(mxn(ratio(e[0], y[0], yn[0]), ratio(e[1], y[1], yn[1])), ratio(eR, yR, ynR)), lane);
     if (err != err || err > 1e300) {
       ++nrej; after_reject = true; h = 0.1 * hs;
-      const double bad = gmax<G>(((y[0] - y[0] != 0.0) || (y[1] - y[1] != 0.0) || (yR - yR != 0.0) || (dgn[0] - dgn[0] != 0.0) || (dgn[1] - dgn[1] != 0.0) ||
-                                  (cin[0] - cin[0] != 0.0) || (cin[1] - cin[1] != 0.0) || (cA - cA != 0.0) || (cB - cB != 0.0) || (cC - cC != 0.0)) ? 1.0 : 0.0, lane);
+      const double bad = gmax<G>(((nonfinite(y[0])) || (nonfinite(y[1])) || (nonfinite(yR)) || (nonfinite(dgn[0])) || (nonfinite(dgn[1])) ||
+                                  (nonfinite(cin[0])) || (nonfinite(cin[1])) || (nonfinite(cA)) || (nonfinite(cB)) || (nonfinite(cC))) ? 1.0 : 0.0, lane);
       if (bad != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
       continue;
     }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
       }
       nacc += (int)nsub;
       tc = te;
-      const double bad = gmax<G>((y - y != 0.0) ? 1.0 : 0.0, lane);      // inf or nan
+      const double bad = gmax<G>((nonfinite(y)) ? 1.0 : 0.0, lane);      // inf or nan
       if (bad != 0.0) { status |= PK_ST_NONFINITE; out.fill_nan(k); break; }
       out.emit(k, y);
     }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
         if (err != err || err > 1e300) {
           // non-finite stage: retry with a much smaller step; give up through the HMIN test above
           ++nrej; after_reject = true; h = 0.1 * hs;
-          if (gmax<G>((y - y != 0.0) ? 1.0 : 0.0, lane) != 0.0) { status |= PK_ST_NONFINITE; out.fill_nan(k); break; }
+          if (gmax<G>((nonfinite(y)) ? 1.0 : 0.0, lane) != 0.0) { status |= PK_ST_NONFINITE; out.fill_nan(k); break; }
           continue;
         }
         double fac = root_q(err, Tab::Q) * (1.0 / 0.9);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
         }
         if (err != err || err > 1e300) {
           ++nrej; h = 0.1 * hs;
-          if (gmax<G>((y - y != 0.0) ? 1.0 : 0.0, lane) != 0.0) { status |= PK_ST_NONFINITE; out.fill_nan(k); break; }
+          if (gmax<G>((nonfinite(y)) ? 1.0 : 0.0, lane) != 0.0) { status |= PK_ST_NONFINITE; out.fill_nan(k); break; }
           continue;
         }
         double fac = ((hist < 2) ? sqrt(err) : cbrt(err)) * (1.0 / 0.9);
@@ -361,6 +361,26 @@ __global__ __launch_bounds__(256) void rhs_kernel(const double* __restrict__ the
   const double yy = (row < S) ? y[rep * S + row] : 0.0;
   const double f = rhs<MODEL, G>(c, yy, n, S, row, lane);
   if (row < S) dydt[rep * S + row] = f;
+}
+
+// Steady state of the affine system: J y* = -b, i.e. W y* = b with W = 0 * I - J -- the same factor / solve pair as an implicit stage
+// with g = 0 (arrow / tridiagonal elimination, dense inverse for the random model).  Replaces the SLSQP feasibility problem of
+// steady/initdist.py:9-50, initsucc.py:9-55, initrand.py:9-77 (which fixes all rates to 1) for ARBITRARY per-replica theta.
+// A singular J (no degradation) yields non-finite values: flagged PK_ST_NONFINITE, row filled with NaN.
+template <int MODEL, int G>
+__global__ __launch_bounds__(256) void steady_kernel(const double* __restrict__ theta, double* __restrict__ yss, int32_t* __restrict__ status,
+                                                     long long B, int n, int S, int P) {
+  const int lane = lane_id();
+  const int row = threadIdx.x & (G - 1);
+  const long long rep = (long long)blockIdx.x * (256 / G) + (threadIdx.x / G);
+  if (rep >= B) return;
+  const RowCoef c = load_row<MODEL>(theta + rep * P, n, S, row);
+  typename SolverFor<MODEL, G, true>::type solver;
+  solver.factor(c, 0.0, S, row, lane);
+  const double x = solver.solve(c.bias, S, row, lane);
+  const double bad = gmax<G>((row < S && (nonfinite(x))) ? 1.0 : 0.0, lane);
+  if (row < S) yss[rep * S + row] = (bad != 0.0) ? __builtin_nan("") : x;
+  if (row == 0 && status) status[rep] = (bad != 0.0) ? PK_ST_NONFINITE : PK_ST_OK;
 }
 
 template <int MODEL, int G>

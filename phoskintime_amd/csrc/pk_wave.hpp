@@ -26,6 +26,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
+// inf or NaN, from the exponent bits.  (The arithmetic idiom `x - x != 0` is NOT safe here: when x is a fresh product a * b the compiler
+// contracts x - x into fma(a, b, -x), the rounding residual of the product, which is non-zero for finite x.)
+__device__ __forceinline__ bool nonfinite(double x) { return (__double2hiint(x) & 0x7ff00000) == 0x7ff00000; }
+
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // broadcast lane K of each group to every lane of that group (K compile-time)

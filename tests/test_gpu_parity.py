@@ -412,3 +412,35 @@ def test_gpu_kernel_matches_independent_c_implementation_of_the_same_algorithm(e
     assert pm.band_error(_np(r.sol), sol_c) <= 0.02
     steps_gpu = _np(r.n_steps)[:, 0]
     assert np.abs(steps_gpu - ns_c[:, 0]).max() <= 2          # the error estimate differs in the last bits only
+
+
+def test_steady_states_and_initial_condition_dropins(eng):
+    """pk_steady_state_protein_batch against the oracle's linear solve on random theta (all three models), the steady.initial_condition
+    drop-ins against the reference's SLSQP outputs, and the singular case (no degradation) flagged rather than returned as garbage."""
+    from pathlib import Path
+    from phoskintime_amd import steady, config
+    rng = np.random.default_rng(31)
+    for model, n in ((0, 1), (0, 4), (0, 30), (1, 1), (1, 2), (1, 14), (2, 1), (2, 3), (2, 4), (2, 5)):
+        P = pm.n_params(model, n)
+        th = rng.uniform(0.05, 20.0, (9, P))
+        y, st = eng.steady_state_batch(model, th, n)
+        assert not _np(st).any()
+        for k in range(9):
+            np.testing.assert_allclose(_np(y)[k], pm.steady_state(model, th[k], n), rtol=1e-11, atol=1e-14)
+        # it is a steady state: the device right-hand side vanishes there
+        f = _np(eng.rhs_batch(model, th, y, n))
+        assert np.abs(f).max() <= 1e-10 * (1.0 + np.abs(th).max())
+    g = np.load(Path(__file__).resolve().parent / "golden" / "steady_init.npz")
+    old = config.ODE_MODEL
+    try:
+        for key in g.files:
+            kind, n = key.split("_n")
+            config.ODE_MODEL = {"initdist": "distmod", "initsucc": "succmod", "initrand": "randmod"}[kind]
+            y = steady.initial_condition(int(n))
+            assert isinstance(y, list) and len(y) == g[key].size
+            np.testing.assert_allclose(y, g[key], rtol=2e-6, atol=1e-9, err_msg=key)
+    finally:
+        config.ODE_MODEL = old
+    th = np.ones((2, 12)); th[1, 1] = 0.0                      # B = 0: mRNA never degrades, no steady state
+    y, st = eng.steady_state_batch(0, th, 4)
+    assert _np(st).tolist() == [0, 1] and np.isnan(_np(y)[1]).all() and np.isfinite(_np(y)[0]).all()

@@ -122,3 +122,16 @@ def test_randmod_rate_quirk():
     dy = pm.rhs(pm.RAND, y, 0.0, theta, n)
     # 0b01 -> 0b11 carries S[lsb(0b11)] = S[0] = 3 (not S[1] = 7), and 0b01 -> P at unit rate
     assert dy[4] == 3.0 and dy[2] == -(3.0 + 1.0) and dy[1] == 1.0
+
+
+def test_steady_state_restatement_matches_reference_slsqp():
+    """oracle.initial_condition (a linear solve) against the lists the reference's SLSQP formulation returned (tests/golden/steady_init.npz,
+    tools/make_golden_steady.py).  SLSQP stops at its own tolerance: 1e-6 relative is what its answers support."""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "steady_init.npz")
+    assert len(g.files) == 16
+    for key in g.files:
+        kind, n = key.split("_n")
+        y = pm.initial_condition(kind, int(n))
+        assert y.shape == g[key].shape
+        np.testing.assert_allclose(y, g[key], rtol=2e-6, atol=1e-9, err_msg=key)
