@@ -444,3 +444,68 @@ def test_steady_states_and_initial_condition_dropins(eng):
     th = np.ones((2, 12)); th[1, 1] = 0.0                      # B = 0: mRNA never degrades, no steady state
     y, st = eng.steady_state_batch(0, th, 4)
     assert _np(st).tolist() == [0, 1] and np.isnan(_np(y)[1]).all() and np.isfinite(_np(y)[0]).all()
+
+
+def test_lambda_scan_and_bootstrap_rows_against_scipy_curve_fit(eng):
+    """find_best_lambda (normest.py:36-166) and the bootstrap loop (normest.py:488-523) as rows of one lockstep batch, against the
+    reference's own flow run on the CPU: scipy.optimize.curve_fit (TRF, x_scale='jac') per (lambda, weighting) on the oracle model,
+    scored with score_fit.  Well-posed synthetic problem (start 15 % off the truth): the optimisers differ, the minima must not."""
+    from scipy.optimize import curve_fit
+    from phoskintime_amd.paramest import find_best_lambda_batch, bootstrap_fit_batch, fit_rows_batch
+    mid, n = pm.DIST, 2
+    true = np.array([1.2, 0.6, 0.9, 0.3, 1.5, 0.7, 0.4, 1.1])
+    P = true.size
+    y0 = np.ones(4)
+    t = pm.TIME_POINTS
+    _, target = pm.solve_ode(mid, true, y0, n, t, rtol=1e-11, atol=1e-12)
+    Nd = target.size
+    p0 = true * (1.0 + 0.15 * np.cos(np.arange(P)))
+    lb, ub = np.full(P, 1e-6), np.full(P, 20.0)
+    weights = {"unit": np.ones(Nd + P), "early_moderate_decay": np.concatenate([np.linspace(1.0, 0.3, Nd), np.ones(P)])}
+    lambdas = np.array([0.01, 1.0])
+    best_lam, best_key, scores = find_best_lambda_batch("distmod", target, p0, t, (lb, ub), y0, n, weights, lambdas=lambdas)
+    assert scores.shape == (2, 2) and best_key in weights and best_lam in lambdas
+    tf = np.concatenate([target, np.zeros(P)])
+    want = np.empty((2, 2))
+    for i, lam in enumerate(lambdas):
+        f = lambda tt, *p, lam=lam: np.concatenate([pm.solve_ode(mid, np.asarray(p), y0, n, t, rtol=1e-10, atol=1e-12)[1], lam / P * np.square(p)])
+        for j, key in enumerate(weights):
+            popt, _ = curve_fit(f, t, tf, p0=p0, bounds=(lb, ub), sigma=weights[key], x_scale="jac", absolute_sigma=True, maxfev=20000)
+            want[i, j] = pm.score_fit(popt, target, pm.solve_ode(mid, popt, y0, n, t)[1])
+    np.testing.assert_allclose(scores, want, rtol=2e-3, atol=1e-6)
+    i, j = np.unravel_index(np.argmin(want), want.shape)
+    assert best_lam == lambdas[i] and best_key == list(weights)[j]
+    # rows with per-row targets / y0 / bounds: two different proteins of the same size in one batch == each alone
+    true2 = true[::-1].copy()
+    _, target2 = pm.solve_ode(mid, true2, y0 * 0.5, n, t, rtol=1e-11, atol=1e-12)
+    both = fit_rows_batch("distmod", n, t, np.stack([p0, p0]), np.stack([y0, y0 * 0.5]), np.stack([target, target2]), bounds=(lb, ub))
+    one = fit_rows_batch("distmod", n, t, p0[None], y0 * 0.5, target2, bounds=(lb, ub))
+    np.testing.assert_allclose(both.p[1], one.p[0], rtol=1e-9)
+    assert both.cost.max() < 1e-10
+    # bootstrap: replicate estimates scatter around the optimum, mean covariance is returned
+    rng = np.random.RandomState(3)
+    pm_mean, pcov, allp = bootstrap_fit_batch("distmod", target, both.p[0], t, (lb, ub), y0, n, bootstraps=6, noise=0.05, rng=rng)
+    assert allp.shape == (6, P) and pcov is not None and pcov.shape == (P, P)
+    assert np.all(np.abs(pm_mean - true) < 0.5 * true + 0.2) and allp.std(axis=0).max() > 0
+
+
+def test_normest_core_pipeline_end_to_end(eng):
+    """lambda scan -> 48-start multistart -> bootstrap -> final solve on synthetic data of a known protein (randmod, log-space fit)."""
+    from phoskintime_amd.paramest import normest_core, build_free_bounds
+    n = 2
+    true = np.array([1.0, 0.5, 0.8, 0.2, 1.0, 0.6, 0.3, 0.4, 0.7])      # randmod n = 2: A,B,C,D,S1,S2,D(1),D(2),D(12)
+    y0 = np.ones(5)
+    _, target = pm.solve_ode(pm.RAND, true, y0, n, pm.TIME_POINTS, rtol=1e-11, atol=1e-12)
+    bounds = {k: (0.0, 20.0) for k in ("A", "B", "C", "D", "S(i)", "D(i)")}
+    lb, ub = build_free_bounds("randmod", bounds, n)
+    assert lb.shape == (9,) and np.allclose(lb, np.log(1e-8)) and np.allclose(ub, np.log(20.0))
+    P, Nd = 9, target.size
+    weights = {"unit": np.ones(Nd + P), "steady_decay": np.concatenate([np.exp(-0.1 * np.tile(np.arange(1, 15), Nd // 14 + 1)[:Nd]), np.ones(P)])}
+    out = normest_core("randmod", "SYN", target, y0, n, pm.TIME_POINTS, bounds, weights, bootstraps=3, n_starts=16, lambdas=np.array([0.01, 0.1]))
+    assert out["weight_key"] in weights and out["lambda_reg"] in (0.01, 0.1)
+    assert out["param_final"].shape == (9,) and out["sol"].shape == (14, 5) and out["fit"].shape == target.shape
+    # the start p0 ~ U(log 1e-8, log 20) of the reference is far from anything (normest.py:389-392); the pipeline must improve on it
+    rs = np.random.RandomState(42)
+    p0 = np.array([rs.uniform(low=l, high=u) for l, u in zip(lb, ub)])
+    err0 = float(np.sum((_np(eng.solve_ode_batch("randmod", np.exp(p0)[None], y0, n, pm.TIME_POINTS).flat)[0] - target) ** 2) / Nd)
+    assert out["error"] < 0.5 * err0 and np.isfinite(out["regularization_term"]) and np.isfinite(out["score"])
