@@ -122,6 +122,17 @@ int pk_jacobian_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
  * called once per protein at paramest/core.py:83) to per-replica theta; S <= 64. */
 int pk_steady_state_protein_batch(pk_ctx*, int model, int n_sites, int64_t B, const double* theta, double* y_ss, int32_t* status);
 
+/* Morris screening without a host round trip (reference: SALib morris.sample / morris.analyze as called at
+ * sensitivity/analysis.py:221-265 and global_model/sensitivity.py:210-277; SALib itself is absent from the reference tree).
+ * The N x D random draws -- base[r,i] on the level grid of the unit cube, sign[r,i] = +-1, rank[r,i] = position of coordinate i in
+ * trajectory r's random order -- come from the host (KB); the N (D + 1) x D sample matrix is built in HBM:
+ *   X[(r (D+1) + s), i] = lb_i + clip(base + sign * delta * [rank < s], 0, 1) * (ub_i - lb_i),       delta = p / (2 (p - 1)).
+ * rank[r, :] must be a permutation of 0..D-1 (not checked on the device).  All pointers are device pointers. */
+int pk_morris_build_batch(pk_ctx*, int64_t N, int D, double delta, const double* base, const double* sign, const int32_t* rank,
+                          const double* lb, const double* ub, double* X);
+/* Elementary effects EE [N,D] from the per-row outputs Y [N (D+1)] of the same design: (Y[r, rank+1] - Y[r, rank]) / (sign * delta). */
+int pk_morris_effects_batch(pk_ctx*, int64_t N, int D, double delta, const double* sign, const int32_t* rank, const double* Y, double* EE);
+
 /* Replaces config.config.score_fit(params, target, prediction, alpha, beta, gamma, delta, mu) (config/config.py:176-226) for B
  * candidates: theta [B,P], target [N] (shared), pred [B,N] (e.g. the `flat` output) -> out [B].  weights = {alpha (rmse), beta (mae),
  * gamma (var), delta (mse), mu (l2)} as a HOST pointer, NULL = all 1 (config/constants.py:77-83). */

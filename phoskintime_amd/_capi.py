@@ -60,7 +60,7 @@ class SolverOpts(C.Structure):
 SYMBOLS = (
     "pk_version", "pk_create", "pk_create_error", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts",
     "pk_protein_n_states", "pk_protein_n_params", "pk_protein_flat_len",
-    "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch", "pk_steady_state_protein_batch", "pk_score_fit_batch",
+    "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch", "pk_steady_state_protein_batch", "pk_morris_build_batch", "pk_morris_effects_batch", "pk_score_fit_batch",
     "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
     "pk_time_solve_protein_batch",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
@@ -110,6 +110,8 @@ def load():
     for f in ("pk_jacobian_protein_batch", "pk_jacobian_protein_batch_host"):
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, i32, i32, i64, vp, vp]
     lib.pk_steady_state_protein_batch.restype = i32; lib.pk_steady_state_protein_batch.argtypes = [vp, i32, i32, i64, vp, vp, vp]
+    lib.pk_morris_build_batch.restype = i32; lib.pk_morris_build_batch.argtypes = [vp, i64, i32, dbl, vp, vp, vp, vp, vp, vp]
+    lib.pk_morris_effects_batch.restype = i32; lib.pk_morris_effects_batch.argtypes = [vp, i64, i32, dbl, vp, vp, vp, vp]
     lib.pk_network_create.restype = vp; lib.pk_network_create.argtypes = [vp, C.POINTER(NetworkDesc)]
     lib.pk_network_destroy.restype = None; lib.pk_network_destroy.argtypes = [vp]
     lib.pk_network_n_states.restype = i32; lib.pk_network_n_states.argtypes = [vp]

@@ -83,13 +83,27 @@ def sensitivity_analysis_batch(popt: Sequence[float], time_points, num_psites: i
     popt = np.asarray(popt, dtype=float)
     problem = (define_sensitivity_problem_rand if model == 'randmod' else define_sensitivity_problem_ds)(num_psites, list(popt))
     if param_values is None:
-        param_values = morris.sample(problem, N=N, num_levels=num_levels, seed=seed)
-    param_values = np.ascontiguousarray(param_values, dtype=float)
-    res = batch.solve_ode_batch(model, param_values, init_cond, num_psites, time_points, want_sol=keep_solutions, want_flat=False,
-                                metric=y_metric, **solver_kw)
-    Y = res.metric.cpu().numpy()
-    Y = np.nan_to_num(Y, nan=0.0, posinf=0.0, neginf=0.0)             # sensitivity/analysis.py:261
-    Si = morris.analyze(problem, param_values, Y, num_levels=num_levels, conf_level=conf_level, scaled=True, seed=seed)
+        # design built in HBM from the draws, outputs reduced to elementary effects on the GPU: only draws (KB) and EE [N, D] cross PCIe
+        Xd, h = morris.sample_device(problem, N=N, num_levels=num_levels, seed=seed)
+        res = batch.solve_ode_batch(model, Xd, init_cond, num_psites, time_points, want_sol=keep_solutions, want_flat=False,
+                                    metric=y_metric, **solver_kw)
+        import torch
+        Yd = torch.nan_to_num(res.metric, nan=0.0, posinf=0.0, neginf=0.0)        # sensitivity/analysis.py:261
+        ee = morris.elementary_effects_device(h, Yd)
+        b = np.asarray(problem["bounds"], float)
+        U = (Xd - h["lb"]) / torch.where(h["ub"] > h["lb"], h["ub"] - h["lb"], torch.ones_like(h["lb"]))
+        sy = float(Yd.std(unbiased=False))
+        scale = (U.std(dim=0, unbiased=False) / sy) if sy > 0 else torch.zeros(U.shape[1], dtype=U.dtype, device=U.device)
+        Si = morris.analyze_effects((ee * scale).cpu().numpy(), problem.get("names"), conf_level=conf_level, seed=seed)
+        param_values = Xd.cpu().numpy()
+        Y = Yd.cpu().numpy()
+    else:
+        param_values = np.ascontiguousarray(param_values, dtype=float)
+        res = batch.solve_ode_batch(model, param_values, init_cond, num_psites, time_points, want_sol=keep_solutions, want_flat=False,
+                                    metric=y_metric, **solver_kw)
+        Y = res.metric.cpu().numpy()
+        Y = np.nan_to_num(Y, nan=0.0, posinf=0.0, neginf=0.0)             # sensitivity/analysis.py:261
+        Si = morris.analyze(problem, param_values, Y, num_levels=num_levels, conf_level=conf_level, scaled=True, seed=seed)
     out = {"problem": problem, "Si": Si, "param_values": param_values, "Y": Y, "status": res.status.cpu().numpy()}
     if keep_solutions:
         sol = res.sol.cpu().numpy()

@@ -509,3 +509,23 @@ def test_normest_core_pipeline_end_to_end(eng):
     p0 = np.array([rs.uniform(low=l, high=u) for l, u in zip(lb, ub)])
     err0 = float(np.sum((_np(eng.solve_ode_batch("randmod", np.exp(p0)[None], y0, n, pm.TIME_POINTS).flat)[0] - target) ** 2) / Nd)
     assert out["error"] < 0.5 * err0 and np.isfinite(out["regularization_term"]) and np.isfinite(out["score"])
+
+
+def test_morris_design_and_elementary_effects_on_the_gpu(eng):
+    """pk_morris_build_batch / pk_morris_effects_batch: the design built in HBM is bit-identical to the host builder; the elementary
+    effects agree with the general host analyser (which re-derives the moved coordinate from X); analytic known answers."""
+    import torch
+    from phoskintime_amd.sensitivity import morris
+    D, N, p_levels = 12, 64, 40
+    problem = {"num_vars": D, "bounds": [[0.1 * i, 1.0 + 0.3 * i] for i in range(D)], "names": [f"x{i}" for i in range(D)]}
+    Xd, h = morris.sample_device(problem, N, p_levels, seed=11)
+    Xh = morris.sample(problem, N, p_levels, seed=11)
+    np.testing.assert_array_equal(_np(Xd), Xh)
+    a = np.linspace(-2.0, 3.0, D)
+    Yd = Xd @ torch.as_tensor(a, device=Xd.device) + 0.5 * Xd[:, 0] * Xd[:, 1]
+    ee = _np(morris.elementary_effects_device(h, Yd))
+    want = morris.elementary_effects(problem, Xh, _np(Yd), p_levels)
+    np.testing.assert_allclose(ee, want, rtol=1e-10, atol=1e-12)
+    width = np.array([b[1] - b[0] for b in problem["bounds"]])
+    np.testing.assert_allclose(ee[:, 2:].mean(axis=0), (a * width)[2:], rtol=1e-10)      # linear terms: EE = a_i * width_i exactly
+    assert ee[:, 0].std() > 0                                                             # the interaction term makes EE_0 vary

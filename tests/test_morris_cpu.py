@@ -108,3 +108,23 @@ def test_multistart_candidates_follow_the_reference_recipe():
     assert not np.array_equal(C1, multistart_candidates("EGFR", base, lb, ub, n_starts=24, seed=42))
     with pytest.raises(ValueError):
         multistart_candidates("x", base, lb, np.full(5, np.inf))
+
+
+def test_vectorised_draws_make_valid_trajectories():
+    """draw() + build(): every trajectory changes each coordinate exactly once by +-delta, stays inside the cube, starts on the grid."""
+    from phoskintime_amd.sensitivity import morris
+    for p_levels, D, N in ((4, 6, 50), (2, 3, 10), (3, 4, 10), (400, 12, 20), (7, 5, 10)):
+        d = morris.draw(D, N, p_levels, seed=5)
+        assert d.base.shape == (N, D) and d.rank.dtype == np.int32
+        assert all(sorted(r) == list(range(D)) for r in d.rank)
+        U = morris.build(d, [[0.0, 1.0]] * D).reshape(N, D + 1, D)
+        assert U.min() >= 0.0 and U.max() <= 1.0
+        grid = np.arange(p_levels) / (p_levels - 1.0)
+        assert np.all(np.min(np.abs(U[:, 0, :, None] - grid[None, None, :]), axis=2) < 1e-12)
+        dU = np.diff(U, axis=1)
+        assert np.all((np.abs(dU) > 1e-12).sum(axis=2) == 1)                      # one coordinate per step
+        assert np.all((np.abs(dU) > 1e-12).sum(axis=1) == 1)                      # each coordinate exactly once
+        np.testing.assert_allclose(np.abs(dU).max(axis=2), d.delta, rtol=1e-12)
+    # both directions and all admissible levels occur
+    d = morris.draw(3, 400, 4, seed=0)
+    assert set(np.unique(d.sign)) == {-1.0, 1.0} and len(np.unique(d.base)) == 4
