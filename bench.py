@@ -161,7 +161,7 @@ def main():
             "solver": {"mean_accepted_steps": nst[0], "mean_rejected_steps": nst[1], "flagged_replicas": status_bad},
         }
         # HBM traffic of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh)
-        pmc = ROOT / "profiles" / "r01_f_dist_fast_lrp8_final_pmc.json"
+        pmc = ROOT / "profiles" / "r01_g_dist_fast_lrp8_pmc.json"
         if pmc.exists() and args.method == "lrp8" and args.linsolve == "auto" and B == 65536:
             pj = json.loads(pmc.read_text())
             res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
