@@ -3,7 +3,7 @@
 
 Workload (config.workload): BASELINE config 3 -- 65 536 parameter vectors theta ~ U(0, 20)^64 (the reference's config bounds,
 config.toml:189-195) per GPU, models.distmod with 30 phosphosites (S = 32), y0 = 1, the reference's 14-point time grid; one
-"step" = one pass of the hot path over that batch: solve (adaptive LRP8 by default, analytic Jacobian) -> clip -> trajectories [B,14,32]
+"step" = one pass of the hot path over that batch: solve (adaptive LRP12 by default, analytic Jacobian) -> clip -> trajectories [B,14,32]
 written to HBM + the fused Morris scalar per replica, then -- for N > 1 -- ONE all-gather (RCCL) of the per-replica scalars.
 Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns its own 65 536 replicas.
 
@@ -36,10 +36,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU (BASELINE config 3: 65536)")
-    ap.add_argument("--rtol", type=float, default=1e-7)
-    ap.add_argument("--atol", type=float, default=1e-9)
+    ap.add_argument("--rtol", type=float, default=None, help="default: 1e-6 for lrp12 (the library default), 1e-7 for the lower-order methods")
+    ap.add_argument("--atol", type=float, default=None, help="default: rtol / 100")
     ap.add_argument("--linsolve", default="auto")
-    ap.add_argument("--method", default="lrp8")
+    ap.add_argument("--method", default="lrp12")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-network", action="store_true", help="skip the secondary network-path measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="replicas in the CPU baseline sample (0 = 128 per core)")
@@ -82,6 +82,10 @@ def main():
                                  n_steps=torch.zeros((B, 2), dtype=torch.int32, device=dev))
     outs = [new_out(), new_out()] if use_dist else [new_out()]
     out = outs[0]
+    if args.rtol is None:
+        args.rtol = 1e-6 if args.method == "lrp12" else 1e-7
+    if args.atol is None:
+        args.atol = args.rtol * 1e-2
     kw = dict(want_flat=False, metric="total_signal", method=args.method, linsolve=args.linsolve, rtol=args.rtol, atol=args.atol)
     main_stream = torch.cuda.current_stream(dev)
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
@@ -155,14 +159,14 @@ def main():
                                                                "; 1 RCCL all-gather of Y per step" if use_dist else ""),
                        "replicas_per_gpu": B, "n_states": S, "n_params": P, "n_timepoints": T, "method": args.method,
                        "parallelism": "replica-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "pk::dist_fast_kernel<8, 4, 3>" if (args.method == "lrp8" and args.linsolve == "auto") else "see config", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": ("pk::dist_fast_kernel<8, 4, %d>" % {"lrp12": 5, "lrp8": 3, "rodas4": 0}[args.method]) if (args.method in ("lrp12", "lrp8", "rodas4") and args.linsolve == "auto") else "see config", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_replica": bytes_per_replica,
                          "note": "path is FP64-VALU/LDS-crossbar bound, not HBM bound (DESIGN.md); HBM fraction reported as the contract asks"},
             "solver": {"mean_accepted_steps": nst[0], "mean_rejected_steps": nst[1], "flagged_replicas": status_bad},
         }
         # HBM traffic of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh)
-        pmc = ROOT / "profiles" / "r01_g_dist_fast_lrp8_pmc.json"
-        if pmc.exists() and args.method == "lrp8" and args.linsolve == "auto" and B == 65536:
+        pmc = ROOT / "profiles" / ("r01_h_dist_fast_lrp12_pmc.json" if args.method == "lrp12" else "r01_g_dist_fast_lrp8_pmc.json")
+        if pmc.exists() and args.method in ("lrp12", "lrp8") and args.linsolve == "auto" and B == 65536 and (args.rtol, args.atol) == ((1e-6, 1e-8) if args.method == "lrp12" else (1e-7, 1e-9)):
             pj = json.loads(pmc.read_text())
             res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
             res["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)" % pmc.name
@@ -173,7 +177,7 @@ def main():
                                  "note": "1024 SIMDs; clock under FP64 load ~2.1 GHz; counters from the same PMC run"}
         # parity on the first 64 replicas of this very batch against the committed SciPy reference trajectories
         gfile = ROOT / "tests" / "golden" / "protein_distmod_n30_c3bounds.npz"
-        if gfile.exists() and args.method in ("rodas4", "lrp8") and B >= 64:
+        if gfile.exists() and args.method in ("rodas4", "lrp8", "lrp12") and B >= 64:
             g = np.load(gfile)
             if np.array_equal(g["theta"], theta_h[:64]):
                 sol64 = out.sol[:64].cpu().numpy()
@@ -193,14 +197,15 @@ def main():
                                              "tolerances -> clip -> flat) on the oracle's numpy-vectorised distmod RHS, one process per core; "
                                              "wall %.1f s" % (nsamp, wall)}
         if not args.no_cpu_baseline and world == 1:
-            # the SAME algorithm (LRP8 + arrow elimination) in scalar C on the host cores: separates what the method buys from what the GPU buys
+            # the SAME algorithm (LRP12 / LRP8 + arrow elimination) in scalar C on the host cores: separates what the method buys from what the GPU buys
             try:
                 from oracle import lrp8_cpu
                 cores = min(os.cpu_count() or 1, 16)
                 nsamp2 = 2048 * cores
-                rate2 = lrp8_cpu.cpu_rate(theta_h[:nsamp2], n_sites, np.ones(S), tgrid, cores)
+                rate2 = lrp8_cpu.cpu_rate(theta_h[:nsamp2], n_sites, np.ones(S), tgrid, cores, stages=(8 if args.method == "lrp8" else 12),
+                                          rtol=args.rtol, atol=args.atol)
                 res["cpu_same_algorithm"] = {"value": rate2, "unit": "replicas/s", "cores": cores, "kind": "port",
-                                             "sample": "first %d replicas; oracle/lrp8_dist.c (gcc -O2, scalar), one process per core" % nsamp2}
+                                             "sample": "first %d replicas; oracle/lrp8_dist.c (gcc -O2, scalar; %s at the same tolerances), one process per core" % (nsamp2, "LRP8" if args.method == "lrp8" else "LRP12")}
             except Exception as e:
                 res["cpu_same_algorithm"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and not args.no_network:

@@ -31,13 +31,15 @@ extern "C" {
 enum { PK_MODEL_DIST = 0, PK_MODEL_SUCC = 1, PK_MODEL_RAND = 2 };
 
 /* Integrators (all adaptive ones: max-norm local error control, steps land exactly on every t[k]).
- * LRP8 is the default: the three per-protein models are affine in y (constant Jacobian), which it exploits. */
+ * LRP12 is the default: the three per-protein models are affine in y (constant Jacobian), which the LRP methods exploit. */
 enum {
   PK_METHOD_RODAS4 = 0, /* 6-stage L-stable Rosenbrock 4(3) (Hairer-Wanner RODAS), analytic Jacobian, 1 factorisation / step */
   PK_METHOD_BDF2   = 1, /* variable-step BDF2 (BDF1 start), analytic Jacobian, 1 factorisation / step (BASELINE config 3) */
   PK_METHOD_RK4    = 2, /* classical explicit RK4, fixed step h <= rk4_h (BASELINE config 2); stability-bound when stiff */
   PK_METHOD_LRP8   = 3, /* L-stable restricted-Pade one-step method for affine systems: 8 resolvent solves, 1 rhs and
                            1 factorisation per step, order 7 with an embedded order-6 estimate */
+  PK_METHOD_LRP12  = 5, /* the same construction with 12 solves: order 11, embedded order 10, gamma = 0.16 (L-stable; |R(iy)| <= 1 + 4.5e-9);
+                           about half the steps of LRP8 at equal accuracy.  Default. */
   PK_METHOD_DP5    = 4  /* pk_network_simulate_batch only: the reference's opt-in explicit integrator, step for step -- Dormand-Prince
                            5(4), PI controller, dt in [1e-6, 1], bucket-edge landing, Hermite output (global_model/solvers.py:293-758) */
 };
@@ -64,7 +66,8 @@ enum {
 typedef struct pk_solver_opts {
   int32_t method;       /* PK_METHOD_*                                                        */
   int32_t linsolve;     /* PK_LINSOLVE_*                                                      */
-  double  rtol, atol;   /* local error tolerances (max-norm); defaults 1e-7 / 1e-9            */
+  double  rtol, atol;   /* local error tolerances (max-norm); defaults 1e-6 / 1e-8 (chosen for LRP12: worst error 0.05 of the
+                           parity band; RODAS4 / LRP8 / BDF2 need 1e-7 / 1e-9 for the same margin) */
   double  h0;           /* first step; 0 = automatic                                          */
   double  rk4_h;        /* RK4 only: largest fixed step (each output interval is split evenly) */
   int32_t max_steps;    /* per replica, accepted + rejected; default 100000                   */

@@ -1,6 +1,6 @@
 /* TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- plain-C, scalar restatement for the distributive model of
  *   (1) the reference right-hand side  models/distmod.py:7-65 (ode_core), and
- *   (2) the ALGORITHM the HIP throughput kernel runs (phoskintime_amd/csrc/pk_dist_fast.hpp): adaptive LRP8 in resolvent form with
+ *   (2) the ALGORITHM the HIP throughput kernel runs (phoskintime_amd/csrc/pk_dist_fast.hpp): adaptive LRP8 / LRP12 in resolvent form with
  *       arrow elimination, same coefficients, same step controller, same landing rule.
  * Purpose: check the GPU kernel against an independent CPU implementation of the same method (agreement far tighter than the
  * parity band), test the method itself on the CPU-only suite, and time "same algorithm on the host cores" next to the GPU
@@ -10,12 +10,19 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define NS 8
-static const double GAM = 0.22;
-static const double LB[NS] = {0.22, 0.896963014494355498137, -4.05804045796110421602, 10.5343409578260650281,
+/* resolvent-form tables (phoskintime_amd/csrc/pk_solve_kernel.hpp ResolventTab; weights from tools/restricted_pade.py) */
+static const double GAM8 = 0.22;
+static const double LB8[8] = {0.22, 0.896963014494355498137, -4.05804045796110421602, 10.5343409578260650281,
                               -11.197471732915163878, 6.15403680296552740685, -1.75732530837770792816, 0.207496723968028089083};
-static const double LE[NS] = {0.0, 0.207496723968028089083, -1.2449803438081685345, 3.11245085952042133624,
+static const double LE8[8] = {0.0, 0.207496723968028089083, -1.2449803438081685345, 3.11245085952042133624,
                               -4.14993447936056178166, 3.11245085952042133624, -1.2449803438081685345, 0.207496723968028089083};
+static const double GAM12 = 0.16;
+static const double LB12[12] = {0.16, 0.610353945449570422947, -5.673096446159684124791, 32.50341628054675047494, -100.569007871288394668,
+                                194.1476904543206939067, -240.6749692517442544225, 197.5042940245258878855, -107.8972269008007496046,
+                                38.02972288281095798187, -7.871184212939898249467, 0.7300070952791203973919};
+static const double LE12[12] = {0.0, 0.7300070952791203973919, -7.300070952791203973919, 32.85031928756041788264, -87.60085143349444768703,
+                                153.3014900086152834523, -183.9617880103383401428, 153.3014900086152834523, -87.60085143349444768703,
+                                32.85031928756041788264, -7.300070952791203973919, 0.7300070952791203973919};
 
 /* models/distmod.py:7-65 */
 void oracle_dist_rhs(const double* y, const double* th, int n, double* dy) {
@@ -49,8 +56,12 @@ static void arrow_solve(const double* r, double* x, const double* th, int n, dou
 
 /* One replica.  Returns status bits (1 non-finite, 2 max steps, 4 step underflow) like the HIP kernels; sol is [T, S] (raw, unclipped). */
 int oracle_lrp8_dist_one(const double* th, int n, const double* y0, const double* t, int T, double rtol, double atol, int max_steps,
-                         double* sol, int* n_acc, int* n_rej) {
+                         int stages, double* sol, int* n_acc, int* n_rej) {
   const int S = n + 2;
+  const int NS = (stages == 12) ? 12 : 8;                 /* LRP12 (default of the library) or LRP8 */
+  const double GAM = (NS == 12) ? GAM12 : GAM8;
+  const double* LB = (NS == 12) ? LB12 : LB8;
+  const double* LE = (NS == 12) ? LE12 : LE8;
   double y[66], yn[66], e[66], z[66], f[66];
   memcpy(y, y0, S * sizeof(double));
   memcpy(sol, y, S * sizeof(double));
@@ -94,7 +105,7 @@ int oracle_lrp8_dist_one(const double* th, int n, const double* y0, const double
         if (nf) { status |= 1; break; }
         continue;
       }
-      double fac = pow(fmin(fmax(err, 1e-30), 1e30), 1.0 / 7.0) / 0.9;
+      double fac = pow(fmin(fmax(err, 1e-30), 1e30), 1.0 / (NS - 1.0)) / 0.9;
       fac = fmax(1.0 / 6.0, fmin(5.0, fac));
       double hnew = hs / fac;
       if (err <= 1.0) {
@@ -115,11 +126,11 @@ int oracle_lrp8_dist_one(const double* th, int n, const double* y0, const double
 
 /* Batch over replicas [b0, b1): theta [B, P], shared y0 [S]; sol [B, T, S]; status / steps may be NULL. */
 void oracle_lrp8_dist_batch(const double* theta, long b0, long b1, int n, const double* y0, const double* t, int T, double rtol, double atol,
-                            int max_steps, double* sol, int32_t* status, int32_t* n_steps) {
+                            int max_steps, int stages, double* sol, int32_t* status, int32_t* n_steps) {
   const int S = n + 2, P = 4 + 2 * n;
   for (long b = b0; b < b1; ++b) {
     int a = 0, r = 0;
-    const int st = oracle_lrp8_dist_one(theta + b * P, n, y0, t, T, rtol, atol, max_steps, sol + (size_t)b * T * S, &a, &r);
+    const int st = oracle_lrp8_dist_one(theta + b * P, n, y0, t, T, rtol, atol, max_steps, stages, sol + (size_t)b * T * S, &a, &r);
     if (status) status[b] = st;
     if (n_steps) { n_steps[2 * b] = a; n_steps[2 * b + 1] = r; }
   }

@@ -8,7 +8,8 @@ template <int G, int RPL>
 static void launch_one(const SolveArgs& a, int method, hipStream_t st) {
   const long long rpb = 256 / G;
   const long long nblk = (a.B + rpb - 1) / rpb;
-  if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((dist_fast_kernel<G, RPL, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((dist_fast_kernel<G, RPL, PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((dist_fast_kernel<G, RPL, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
   else                          hipLaunchKernelGGL((dist_fast_kernel<G, RPL, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
 }
 

@@ -11,7 +11,8 @@ static void launch_nb(const SolveArgs& a, int method, hipStream_t st) {
   constexpr int G = (1 << NB) < 4 ? 4 : (1 << NB);
   const long long rpb = 256 / G;
   const long long nblk = (a.B + rpb - 1) / rpb;
-  if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
   else                          hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
 }
 
@@ -27,7 +28,8 @@ void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {
       static const bool g32 = getenv("PK_RAND5_G32") && atoi(getenv("PK_RAND5_G32")) != 0;
       if (g32) { launch_nb<5>(a, method, st); break; }
       const long long nblk = (a.B + 15) / 16;
-      if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+      if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+      else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
       else                          hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
     } break;
   }

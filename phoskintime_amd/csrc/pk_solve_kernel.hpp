@@ -64,6 +64,24 @@ template <> struct ResolventTab<PK_METHOD_LRP8> {
                                   -4.14993447936056178166, 3.11245085952042133624, -1.2449803438081685345, 0.207496723968028089083};
 };
 
+// LRP12: 12 resolvent solves, order 11, embedded order 10 on z_1..z_11; gamma = 0.16.  R(inf) = 0 (L-stable); the embedded method is
+// strictly A-stable; the propagated one is A(alpha)-stable with alpha = 90 deg to within its own leading error term: on the imaginary
+// axis |R(iy)| <= 1 + 4.5e-9, the excess sitting at |y| ~ 1 (2 C_12 y^12 with C_12 = 8.7e-10 > 0) and |R(iy)| < 1 beyond (tools/
+// restricted_pade.py 12 0.16; tests/test_integrator_tables.py).  For comparison the reference's LSODA switches to BDF1-5 (alpha = 73 deg
+// at order 4, 51 deg at order 5).  The models' Jacobians are (similar to) M-matrices with real spectra, where only |R(x)| <= 1, x <= 0, matters.  Weights alternate in sign up to ~240: three digits of cancellation
+// against double precision's sixteen, five orders of magnitude below the parity band.
+template <> struct ResolventTab<PK_METHOD_LRP12> {
+  static constexpr int NS = 12;
+  static constexpr double GAM = 0.16;
+  static constexpr double Q = 11.0;
+  static constexpr double B[12] = {0.16, 0.610353945449570422947, -5.673096446159684124791, 32.50341628054675047494, -100.569007871288394668,
+                                   194.1476904543206939067, -240.6749692517442544225, 197.5042940245258878855, -107.8972269008007496046,
+                                   38.02972288281095798187, -7.871184212939898249467, 0.7300070952791203973919};
+  static constexpr double E[12] = {0.0, 0.7300070952791203973919, -7.300070952791203973919, 32.85031928756041788264, -87.60085143349444768703,
+                                   153.3014900086152834523, -183.9617880103383401428, 153.3014900086152834523, -87.60085143349444768703,
+                                   32.85031928756041788264, -7.300070952791203973919, 0.7300070952791203973919};
+};
+
 // err^(1/Q) for the step-size controller: single precision is ample (the factor is clamped to [1/6, 5] anyway)
 __device__ __forceinline__ double root_q(double err, double Q) {
   const float e = (float)fmin(fmax(err, 1e-30), 1e30);
@@ -199,9 +217,9 @@ __global__ __launch_bounds__(256) void solve_kernel(const SolveArgs A) {
       if (!(h > 0.0) || h != h) h = 1e-6;
     }
 
-    if constexpr (METHOD == PK_METHOD_RODAS4 || METHOD == PK_METHOD_LRP8) {
+    if constexpr (METHOD == PK_METHOD_RODAS4 || METHOD == PK_METHOD_LRP8 || METHOD == PK_METHOD_LRP12) {
       using namespace r4;
-      constexpr bool RES = RESOLVENT || METHOD == PK_METHOD_LRP8;
+      constexpr bool RES = RESOLVENT || METHOD == PK_METHOD_LRP8 || METHOD == PK_METHOD_LRP12;
       using Tab = ResolventTab<METHOD>;
       constexpr double GAMMA = Tab::GAM;
       bool after_reject = false;

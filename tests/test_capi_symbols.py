@@ -40,7 +40,7 @@ def test_shapes(built_lib):
 def test_default_opts_struct_layout(built_lib):
     from phoskintime_amd import _capi
     o = _capi.default_opts()
-    assert (o.method, o.linsolve, o.rtol, o.atol, o.max_steps, o.clip_nonneg, o.normalize) == (3, 0, 1e-7, 1e-9, 100000, 1, 0)
+    assert (o.method, o.linsolve, o.rtol, o.atol, o.max_steps, o.clip_nonneg, o.normalize) == (5, 0, 1e-6, 1e-8, 100000, 1, 0)
     assert C.sizeof(_capi.SolverOpts) == 56
     o = _capi.default_opts(method="bdf2", linsolve="dense", rtol=1e-9)
     assert (o.method, o.linsolve, o.rtol) == (1, 1, 1e-9)

@@ -68,27 +68,39 @@ def test_rodas4_resolvent_weights_match_source():
     assert abs(1 + sum(rr.beta[k] * zi / (1 - rr.g * zi) ** (k + 1) for k in range(6))) < mp.mpf("1e-7")
 
 
-def test_lrp8_weights_rederived_and_a_stable():
+@pytest.mark.parametrize("name,s_,gam", [("PK_METHOD_LRP8", 8, "0.22"), ("PK_METHOD_LRP12", 12, "0.16")])
+def test_lrp_weights_rederived_and_a_stable(name, s_, gam):
     mp.mp.dps = 60
     src = (CSRC / "pk_solve_kernel.hpp").read_text()
     rp = _load("restricted_pade")
-    blk = src[src.index("struct ResolventTab<PK_METHOD_LRP8>"):]
+    blk = src[src.index("struct ResolventTab<%s>" % name):]
+    blk = blk[:blk.index("\n};")]
     g = _literals(blk, "GAM")[0]
-    assert g == mp.mpf("0.22")
+    assert g == mp.mpf(gam)
     B = _literals(blk, "B"); E = _literals(blk, "E")
-    beta = rp.solve_weights(8, g, 7)
-    bh = rp.solve_weights(8, g, 6, extra_zero=(8,))
-    for k in range(8):
+    assert len(B) == s_ and len(E) == s_ and _literals(blk, "NS")[0] == s_ and _literals(blk, "Q")[0] == s_ - 1
+    beta = rp.solve_weights(s_, g, s_ - 1)
+    bh = rp.solve_weights(s_, g, s_ - 2, extra_zero=(s_,))
+    for k in range(s_):
         assert abs(B[k] - beta[k]) < mp.mpf("2e-15") * max(1, abs(beta[k]))
         assert abs(E[k] - (beta[k] - bh[k])) < mp.mpf("2e-15") * max(1, abs(beta[k]))
-    # order: R(z) - exp(z) = O(z^8) ; embedded O(z^7)
+    # order: R(z) - exp(z) = O(z^s) ; embedded O(z^(s-1))
     z = mp.mpf("0.05")
-    assert abs(rp.R(beta, g, z) - mp.e ** z) < 1e-3 * z ** 8 * 100
-    assert abs(rp.R(bh, g, z) - mp.e ** z) < 1e-2 * z ** 7 * 100
+    assert abs(rp.R(beta, g, z) - mp.e ** z) < 1e-3 * z ** s_ * 100
+    assert abs(rp.R(bh, g, z) - mp.e ** z) < 1e-2 * z ** (s_ - 1) * 100
     # L-stability and A-stability (poles sit at 1/gamma > 0; on the imaginary axis |R| <= 1)
     assert abs(rp.R(beta, g, mp.mpf("-1e12"))) < mp.mpf("1e-10") and abs(rp.R(bh, g, mp.mpf("-1e12"))) < mp.mpf("1e-10")
-    assert rp.a_stable(beta, g, n=1500) <= 1 + mp.mpf("1e-20")
+    # LRP8: strictly A-stable.  LRP12: the embedded method strictly, the propagated one up to its own leading error term
+    # (|R(iy)|^2 - 1 ~ 2 C_12 y^12 with C_12 > 0 near |y| ~ 1): |R(iy)| <= 1 + 4.5e-9, as the source comment states
+    assert rp.a_stable(beta, g, n=1500) <= 1 + (mp.mpf("1e-20") if s_ == 8 else mp.mpf("4.6e-9"))
     assert rp.a_stable(bh, g, n=1500) <= 1 + mp.mpf("1e-20")
+    if s_ == 12:
+        assert all(abs(rp.R(beta, g, mp.mpc(0, y))) < 1 for y in (2, 3, 5, 10, 100, 1e4))
+        assert all(abs(rp.R(beta, g, mp.mpf(-x))) <= 1 for x in (1e-3, 0.1, 1, 3, 10, 100, 1e6))       # the negative real axis
+    # the scalar-C oracle carries the same tables
+    csrc = (CSRC.parents[1] / "oracle" / "lrp8_dist.c").read_text()
+    cb = _literals(csrc, "LB%d" % s_); ce = _literals(csrc, "LE%d" % s_)
+    assert [float(x) for x in cb] == [float(x) for x in B] and [float(x) for x in ce] == [float(x) for x in E]
 
 
 def test_ros34pw2_table_satisfies_w_conditions_and_matches_source():

@@ -26,10 +26,11 @@ def test_c_lrp8_within_band_of_reference_tight(golden_files):
         K = min(g["theta"].shape[0], 16)
         if not np.all(g["y0"][:K] == g["y0"][0]):
             K = 1
-        sol, st, ns = lrp8_cpu.solve_batch(g["theta"][:K], n, g["y0"][0], g["t"])
-        assert not st.any()
-        worst = max(worst, pm.band_error(sol, g["sol_tight"][:K]))
-        assert 20 <= ns[:, 0].mean() <= 120
+        for kw, lo, hi in (({}, 10, 60), ({"stages": 8, "rtol": 1e-7, "atol": 1e-9}, 20, 120)):      # LRP12 at the defaults, LRP8 at 1e-7
+            sol, st, ns = lrp8_cpu.solve_batch(g["theta"][:K], n, g["y0"][0], g["t"], **kw)
+            assert not st.any()
+            worst = max(worst, pm.band_error(sol, g["sol_tight"][:K]))
+            assert lo <= ns[:, 0].mean() <= hi
     assert worst <= 0.1
 
 

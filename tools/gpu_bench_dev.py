@@ -39,6 +39,13 @@ if __name__ == '__main__':
             for nb in (1, 2, 3, 4, 5):
                 run(2, nb, 65536, meth, 'auto')
             run(0, 4, 65536, meth, 'auto')
+    if which in ('all', 'lrp12'):
+        for meth, rt, at in (('lrp8', 1e-7, 1e-9), ('lrp12', 1e-6, 1e-8), ('lrp12', 1e-7, 1e-9), ('lrp8', 1e-6, 1e-8)):
+            run(0, 30, 65536, meth, 'auto', rtol=rt, atol=at)
+            run(0, 4, 65536, meth, 'auto', rtol=rt, atol=at)
+            run(1, 14, 65536, meth, 'auto', rtol=rt, atol=at)
+            run(2, 4, 65536, meth, 'auto', rtol=rt, atol=at)
+            run(2, 5, 65536, meth, 'auto', rtol=rt, atol=at)
     if which in ('all', 'rand'):
         for nb in (4, 5, 6):
             run(2, nb, 65536 if nb < 6 else 16384, 'lrp8', 'auto')
