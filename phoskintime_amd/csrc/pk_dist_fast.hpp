@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void dist_fast_kernel(const SolveArgs A) {
   const double rtol = A.rtol, atol = A.atol;
   // max-norm helpers over the whole system (sites of this lane + shadows, then across the group)
   auto group_max = [&](const Trk<RPL>& num, const Trk<RPL>& a, const Trk<RPL>& b) {
-    auto q = [&](double e, double ya, double yb) { return fabs(e) * fast_rcp(__builtin_fma(rtol, fmax(fabs(ya), fabs(yb)), atol)); };
+    auto q = [&](double e, double ya, double yb) { return fabs(e) * approx_rcp(__builtin_fma(rtol, fmax(fabs(ya), fabs(yb)), atol)); };
     auto mx = [](double p, double r) { return (p > r || p != p) ? p : r; };
     double m = mx(q(num.R, a.R, b.R), q(num.P, a.P, b.P));
 #pragma unroll

@@ -18,6 +18,10 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// 1/x from v_rcp_f64 alone (relative error ~1e-8): for quantities that only steer the step-size controller (error ratios), where one
+// instruction instead of seven is worth more than the last eight digits
+__device__ __forceinline__ double approx_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+
 // Dense, explicit inverse: in-register Gauss-Jordan (no pivoting, same M-matrix argument), then every solve is a
 // mat-vec whose G broadcasts are independent of each other.  The first version of this solver (LU + two triangular solves per
 // right-hand side) was bound by the 2G-long dependent chain of cross-lane broadcasts: 363 ms vs 29 ms on config 3.

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void rand_fast_kernel(const SolveArgs A) {
   if (T < 2) { finish(status, 0, 0); return; }
 
   const double rtol = A.rtol, atol = A.atol;
-  auto ratio = [&](double e, double ya, double yb) { return fabs(e) * fast_rcp(__builtin_fma(rtol, fmax(fabs(ya), fabs(yb)), atol)); };
+  auto ratio = [&](double e, double ya, double yb) { return fabs(e) * approx_rcp(__builtin_fma(rtol, fmax(fabs(ya), fabs(yb)), atol)); };
   auto mxn = [](double p, double r) { return (p > r || p != p) ? p : r; };
   // f(Y) for this lane's row and for the shadow row
   auto rhs_row = [&](const double Y, const double YR) {

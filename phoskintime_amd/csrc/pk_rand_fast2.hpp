@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void rand_fast2_kernel(const SolveArgs A) {
   if (T < 2) { finish(status, 0, 0); return; }
 
   const double rtol = A.rtol, atol = A.atol;
-  auto ratio = [&](double e, double ya, double yb) { return fabs(e) * fast_rcp(__builtin_fma(rtol, fmax(fabs(ya), fabs(yb)), atol)); };
+  auto ratio = [&](double e, double ya, double yb) { return fabs(e) * approx_rcp(__builtin_fma(rtol, fmax(fabs(ya), fabs(yb)), atol)); };
   auto mxn = [](double p, double r) { return (p > r || p != p) ? p : r; };
   // f(Y) of the lane's two rows.  Bits 0..3: XOR partner lanes, same slot; bit 4: the lane's other slot.
   auto rhs_rows = [&](const double (&Y)[2], const double YR, double (&f)[2]) {
