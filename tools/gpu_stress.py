@@ -8,7 +8,7 @@ from oracle import protein_models as pm
 rng = np.random.default_rng(123)
 worst = {}
 cases = []
-for model, ns in ((0, (1, 3, 7, 15, 31, 47, 62)), (1, (1, 2, 5, 13, 29, 62)), (2, (1, 2, 3, 4, 5))):
+for model, ns in ((0, (1, 3, 7, 15, 31, 47, 62)), (1, (1, 2, 5, 13, 29, 62)), (2, (1, 2, 3, 4, 5, 6))):
     for n in ns:
         cases.append((model, n))
 for model, n in cases:
