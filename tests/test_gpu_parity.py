@@ -533,3 +533,24 @@ def test_morris_design_and_elementary_effects_on_the_gpu(eng):
     width = np.array([b[1] - b[0] for b in problem["bounds"]])
     np.testing.assert_allclose(ee[:, 2:].mean(axis=0), (a * width)[2:], rtol=1e-10)      # linear terms: EE = a_i * width_i exactly
     assert ee[:, 0].std() > 0                                                             # the interaction term makes EE_0 vary
+
+
+def test_full_size_config2_properties(eng):
+    """BASELINE config 2 at full size (4 096 replicas of the 16-state successive model), both parameter regimes it names:
+    unflagged, finite, closed-form agreement on a subsample, LTI superposition, and flat = the reference's observable layout of sol."""
+    model, n, B = pm.SUCC, 14, 4096
+    P, S = 32, 16
+    for seed, lo, hi in ((20260515 + 1, 0.0, 20.0), (20260515 + 1001, 0.05, 2.0)):
+        rng = np.random.default_rng(seed)
+        theta = rng.uniform(lo, hi, (B, P))
+        r = eng.solve_ode_batch(model, theta, np.ones(S), n, pm.TIME_POINTS, clip_nonneg=False)
+        sol, flat = _np(r.sol), _np(r.flat)
+        assert not _np(r.status).any() and np.isfinite(sol).all()
+        for b in rng.choice(B, 16, replace=False):
+            assert pm.band_error(sol[b], pm.solve_exact_lti(model, theta[b], np.ones(S), n, pm.TIME_POINTS)) <= 0.1
+            np.testing.assert_array_equal(flat[b], pm.flatten_observables(model, sol[b], n))
+        a = rng.uniform(0, 1, S)
+        sa = _np(eng.solve_ode_batch(model, theta, a, n, pm.TIME_POINTS, clip_nonneg=False, want_flat=False).sol)
+        sb = _np(eng.solve_ode_batch(model, theta, 1.0 - a, n, pm.TIME_POINTS, clip_nonneg=False, want_flat=False).sol)
+        s0 = _np(eng.solve_ode_batch(model, theta, np.zeros(S), n, pm.TIME_POINTS, clip_nonneg=False, want_flat=False).sol)
+        assert pm.band_error(sa + sb - s0, sol) <= 0.5
