@@ -198,6 +198,16 @@ int pk_network_simulate_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int 
 /* global_model.params.unpack_params (softplus of the raw decision vectors): x_raw [B,n_var] -> x_phys [B,n_var]. */
 int pk_network_unpack_batch(pk_ctx*, pk_net*, int64_t B, const double* x_raw, double* x_phys);
 
+/* Discrete Frechet distance between observed and predicted curves for B candidates x n_series series -- replaces
+ * frechet.distance.frechet_distance (frechet/distance.py:9-56) inside the Pareto pick loop of global_model/runner.py:780-841.
+ * Series s compares the observed points (obs_t, obs_v)[obs_ptr[s] .. obs_ptr[s+1]) with the predicted points
+ * (pred_t[k], pred[b, pred_idx[k]]) for k in [pred_ptr[s], pred_ptr[s+1]); points are 2-D (time, value), both lists sorted by time by the
+ * caller; pred [B, n_obs] is e.g. the output of pk_network_observables_batch.  max_points = longest curve (<= 32; checked here because
+ * the kernel keeps the DP row in registers).  out [B, n_series]; a series with an empty side gives 0.  All pointers device pointers. */
+int pk_frechet_batch(pk_ctx*, int64_t B, int n_series, const int32_t* obs_ptr, const double* obs_t, const double* obs_v,
+                     const int32_t* pred_ptr, const double* pred_t, const int32_t* pred_idx, const double* pred, int n_obs,
+                     int max_points, double* out);
+
 /* Fused objective of one optimiser candidate after the simulation -- replaces global_model.lossfn.LOSS_FN (lossfn.py:114-382; all eight
  * LOSS_MODEs) and the assembly in GlobalODE_MOO._evaluate (optproblem.py:99-160).  pk_loss_data mirrors cache.prepare_fast_loss_data's
  * arrays (HOST pointers, copied to HBM and index-checked by pk_network_loss_create for a time grid of T points).

@@ -449,3 +449,20 @@ def objectives(net: Network, x_phys, defaults, Y, ld: dict, mode: int, lambdas: 
     norm = lambda w: 1.0 / max(1e-6, float(np.sum(w)))
     return np.array([lp * norm(ld["w_prot"]) * lambdas["protein"] + prior, lr * norm(ld["w_rna"]) * lambdas["rna"] + prior,
                      lph * norm(ld["w_pho"]) * lambdas["phospho"] + prior])
+
+
+def frechet_distance(true_coords, pred_coords) -> float:
+    """frechet/distance.py:9-56: pairwise Euclidean distances of the points, then c[i][j] = max(min(c[i-1][j], c[i][j-1], c[i-1][j-1]), d[i][j])."""
+    a = np.asarray(true_coords, float); b = np.asarray(pred_coords, float)
+    n, m = len(a), len(b)
+    d = np.sqrt(((a[:, None, :] - b[None, :, :]) ** 2).sum(axis=2))
+    c = np.full((n, m), np.inf)
+    c[0, 0] = d[0, 0]
+    for i in range(1, n):
+        c[i, 0] = max(c[i - 1, 0], d[i, 0])
+    for j in range(1, m):
+        c[0, j] = max(c[0, j - 1], d[0, j])
+    for i in range(1, n):
+        for j in range(1, m):
+            c[i, j] = max(min(c[i - 1, j], c[i, j - 1], c[i - 1, j - 1]), d[i, j])
+    return float(c[-1, -1])

@@ -65,7 +65,7 @@ SYMBOLS = (
     "pk_time_solve_protein_batch",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
-    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_observables_batch",
+    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_observables_batch", "pk_frechet_batch",
 )
 
 _lib = None
@@ -112,6 +112,7 @@ def load():
     lib.pk_steady_state_protein_batch.restype = i32; lib.pk_steady_state_protein_batch.argtypes = [vp, i32, i32, i64, vp, vp, vp]
     lib.pk_morris_build_batch.restype = i32; lib.pk_morris_build_batch.argtypes = [vp, i64, i32, dbl, vp, vp, vp, vp, vp, vp]
     lib.pk_morris_effects_batch.restype = i32; lib.pk_morris_effects_batch.argtypes = [vp, i64, i32, dbl, vp, vp, vp, vp]
+    lib.pk_frechet_batch.restype = i32; lib.pk_frechet_batch.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.pk_network_create.restype = vp; lib.pk_network_create.argtypes = [vp, C.POINTER(NetworkDesc)]
     lib.pk_network_destroy.restype = None; lib.pk_network_destroy.argtypes = [vp]
     lib.pk_network_n_states.restype = i32; lib.pk_network_n_states.argtypes = [vp]

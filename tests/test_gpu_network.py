@@ -517,3 +517,67 @@ def test_full_size_network_config4_morris():
     np.testing.assert_allclose(Sp["mu_star"], Si["mu_star"], rtol=1e-12, atol=1e-14)
     print("config-4-sized network Morris: %d simulations, wall %.2f s" % (B, wall))
     eng.close()
+
+
+def test_frechet_distance_kernel_and_population_pick():
+    """pk_frechet_batch against the reference's frechet_distance outputs (tests/golden/frechet.npz), batched series against the oracle,
+    and the whole Pareto pick (simulate -> fold changes -> per-series Frechet -> weighted sum -> argmin) against a host composition."""
+    from phoskintime_amd.frechet import frechet_distance, frechet_batch
+    from phoskintime_amd.global_model import NetworkEngine
+    from phoskintime_amd.global_model.pick import frechet_pick_batch
+    g = np.load(GOLD[0].parent / "frechet.npz")
+    K = g["dist"].size
+    for k in range(K):
+        assert abs(frechet_distance(g[f"a{k}"], g[f"b{k}"]) - g["dist"][k]) <= 1e-12 * max(1.0, g["dist"][k])
+    # all K series in one launch, 3 candidates whose predicted values differ
+    rng = np.random.default_rng(2)
+    obs = [g[f"a{k}"] for k in range(K)]
+    pt = [g[f"b{k}"][:, 0] for k in range(K)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in pt])])
+    pidx = [offs[k] + np.arange(len(pt[k])) for k in range(K)]
+    base = np.concatenate([g[f"b{k}"][:, 1] for k in range(K)])
+    pred = np.stack([base, base * 1.3, rng.uniform(0.2, 3.0, base.size)])
+    out = frechet_batch(obs, pt, pidx, pred).cpu().numpy()
+    np.testing.assert_allclose(out[0], g["dist"], rtol=1e-12)
+    for b in (1, 2):
+        want = [nm.frechet_distance(obs[k], np.stack([pt[k], pred[b, pidx[k]]], axis=1)) for k in range(K)]
+        np.testing.assert_allclose(out[b], want, rtol=1e-12)
+    with pytest.raises(ValueError):
+        frechet_batch([np.zeros((40, 2))], [np.zeros(3)], [np.arange(3)], np.zeros((1, 3)))
+    # population pick on a golden network
+    gn = np.load([x for x in GOLD if x.name == "network_m0_small.npz"][0])
+    eng = NetworkEngine.from_npz(gn)
+    X = np.stack([_x(eng, gn, k) for k in range(4)])
+    tp = gn["kin_grid"]; tr = np.array([4.0, 8.0, 15.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
+    times = np.unique(np.concatenate([tp, tr]))
+    Y, _, _ = eng.simulate_batch(X, times, rtol=1e-5, atol=1e-7)
+    Y = Y.cpu().numpy()
+    fc = lambda y, base: np.maximum(y, 1e-12) / np.maximum(base, 1e-12)
+    sel = lambda tt: np.where(np.isin(times, tt))[0]
+    # observations = candidate 2's own curves with a few points dropped: candidate 2 must win with the smallest score
+    obs_prot, obs_rna, obs_pho = {}, {}, {}
+    oy, os_, nsites = gn["offset_y"], gn["offset_s"], gn["n_sites"]
+    tot = lambda Yb, i: Yb[:, oy[i] + 1:oy[i] + 2 + nsites[i]].sum(axis=1)
+    for i in range(int(gn["N"])):
+        P = tot(Y[2], i)
+        cur = np.stack([tp, fc(P[sel(tp)], P[0])], axis=1)
+        obs_prot[i] = cur[::2] if i % 2 else cur
+        R = Y[2][:, oy[i]]
+        obs_rna[i] = np.stack([tr, fc(R[sel(tr)], R[np.where(times == 4.0)[0][0]])], axis=1)
+        for j in range(int(nsites[i])):
+            ph = Y[2][:, oy[i] + 2 + j]
+            obs_pho[(i, j)] = np.stack([tp, fc(ph[sel(tp)], ph[0])], axis=1)
+    res = frechet_pick_batch(eng, X, tp, tr, tp, obs_prot, obs_rna, obs_pho, lambdas=(1.0, 0.5, 2.0))
+    assert res["best"] == 2 and res["per_series"].shape == (4, len(res["series"])) and not res["status"].any()
+    # host composition for candidate 0
+    want = 0.0
+    for (kind, key), w in zip(res["series"], [1.0 if s[0] == "prot" else 0.5 if s[0] == "rna" else 2.0 for s in res["series"]]):
+        if kind == "prot":
+            P = tot(Y[0], key); pc = np.stack([tp, fc(P[sel(tp)], P[0])], axis=1); oc = obs_prot[key]
+        elif kind == "rna":
+            R = Y[0][:, oy[key]]; pc = np.stack([tr, fc(R[sel(tr)], R[np.where(times == 4.0)[0][0]])], axis=1); oc = obs_rna[key]
+        else:
+            ph = Y[0][:, oy[key[0]] + 2 + key[1]]; pc = np.stack([tp, fc(ph[sel(tp)], ph[0])], axis=1); oc = obs_pho[key]
+        want += w * nm.frechet_distance(oc, pc)
+    assert abs(res["scores"][0] - want) <= 1e-9 * max(1.0, want)
+    eng.close()

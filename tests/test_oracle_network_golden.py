@@ -75,3 +75,9 @@ def test_oracle_rk45_restatement_reproduces_the_reference_integrator(m):
     np.testing.assert_allclose(Y, g["Y_rk45_tight"][0], rtol=1e-13, atol=1e-15)
     # the explicit method at its default tolerance is ~1e-5 from the truth; at 1e-9 it agrees with LSODA at 1e-12
     assert np.abs(g["Y_rk45_tight"][0] - g["Y_tight"][0]).max() < 1e-7
+
+
+def test_oracle_frechet_restatement_matches_reference():
+    g = np.load(GOLD[0].parent / "frechet.npz")
+    for k in range(g["dist"].size):
+        assert abs(nm.frechet_distance(g[f"a{k}"], g[f"b{k}"]) - g["dist"][k]) <= 1e-12 * max(1.0, g["dist"][k])
