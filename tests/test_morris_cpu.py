@@ -128,3 +128,31 @@ def test_vectorised_draws_make_valid_trajectories():
     # both directions and all admissible levels occur
     d = morris.draw(3, 400, 4, seed=0)
     assert set(np.unique(d.sign)) == {-1.0, 1.0} and len(np.unique(d.base)) == 4
+
+
+def test_on_disk_artefacts_have_the_reference_layouts(tmp_path):
+    """pareto_X/F, sensitivity_indices.csv, fitted_params_picked.json, picked_objectives.json (runner.py:734-743, 912-929;
+    global_model/sensitivity.py:266-281) -- file names, columns, ordering."""
+    import json
+    import pandas as pd
+    from phoskintime_amd.global_model import export
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(5, 7)); F = rng.uniform(size=(5, 3))
+    out = str(tmp_path / "run")
+    export.save_pareto(out, X, F)
+    np.testing.assert_array_equal(np.load(out + "/pareto_X.npy"), X)
+    np.testing.assert_array_equal(np.load(out + "/pareto_F.npy"), F)
+    df = pd.read_csv(out + "/pareto_F.csv")
+    assert list(df.columns) == ["prot_mse", "rna_mse", "phospho_mse"] and np.allclose(df.values, F)
+    problem = {"names": ["a", "b", "c"]}
+    Si = {"mu_star": np.array([0.1, 3.0, 1.0]), "sigma": np.array([1.0, 2.0, 3.0]), "mu_star_conf": np.array([0.01, 0.02, 0.03])}
+    path = export.save_sensitivity_indices(out, problem, Si)
+    ds = pd.read_csv(path)
+    assert list(ds.columns) == ["Parameter", "mu_star", "sigma", "mu_star_conf"] and list(ds["Parameter"]) == ["b", "c", "a"]
+    params = {"c_k": np.array([1.0, 2.0]), "tf_scale": 0.3}
+    dfp = pd.DataFrame({"protein": ["P1"], "time": [0.0], "pred_fc": [1.0]})
+    picked = export.save_picked(out, params, F, 2, lambdas=(1.0, 0.5, 2.0), df_prot=dfp)
+    assert json.load(open(out + "/fitted_params_picked.json")) == {"c_k": [1.0, 2.0], "tf_scale": 0.3}
+    po = json.load(open(out + "/picked_objectives.json"))
+    assert po == picked and abs(po["scalar_score"] - (F[2, 0] + 0.5 * F[2, 1] + 2.0 * F[2, 2])) < 1e-15
+    assert list(pd.read_csv(out + "/pred_prot_picked.csv").columns) == ["protein", "time", "pred_fc"]
