@@ -33,8 +33,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec sheet; 256 CU x 4
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU (BASELINE config 3: 65536)")
     ap.add_argument("--rtol", type=float, default=None, help="default: 1e-6 for lrp12 (the library default), 1e-7 for the lower-order methods")
     ap.add_argument("--atol", type=float, default=None, help="default: rtol / 100")
