@@ -554,3 +554,22 @@ def test_full_size_config2_properties(eng):
         sb = _np(eng.solve_ode_batch(model, theta, 1.0 - a, n, pm.TIME_POINTS, clip_nonneg=False, want_flat=False).sol)
         s0 = _np(eng.solve_ode_batch(model, theta, np.zeros(S), n, pm.TIME_POINTS, clip_nonneg=False, want_flat=False).sol)
         assert pm.band_error(sa + sb - s0, sol) <= 0.5
+
+
+def test_integration_md_binding_stub_runs_as_written(eng, golden_files):
+    """The ctypes stub INTEGRATION.md shows a maintainer (section 3) is executed verbatim (only the library path is made absolute)
+    and must reproduce the maintained binding bit for bit."""
+    import re
+    from pathlib import Path
+    from phoskintime_amd import _capi
+    root = Path(__file__).resolve().parents[1]
+    md = (root / "INTEGRATION.md").read_text()
+    code = re.search(r"```python\n(.*?)```", md, re.S).group(1)
+    code = code.replace('"libphoskin_hip.so"', repr(str(_capi.LIB_PATH)))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g, model, n = _load([x for x in golden_files if x.name == "protein_distmod_n4_real.npz"][0])
+    sol, flat = ns["solve_ode_batch"]("distmod", g["theta"], g["y0"][0], n, g["t"])
+    r = eng.solve_ode_batch(model, g["theta"], g["y0"][0], n, g["t"])
+    np.testing.assert_array_equal(sol, _np(r.sol))
+    np.testing.assert_array_equal(flat, _np(r.flat))
