@@ -581,3 +581,20 @@ def test_frechet_distance_kernel_and_population_pick():
         want += w * nm.frechet_distance(oc, pc)
     assert abs(res["scores"][0] - want) <= 1e-9 * max(1.0, want)
     eng.close()
+
+
+def test_network_beyond_the_register_kernel_limits_runs_through_the_lds_kernel():
+    """N = 300 proteins (> 256) and S = 1000 states: the register kernel is not eligible, the LDS kernel must take over and agree with the
+    explicit DP5 path (right-hand sides only) run at a tight tolerance."""
+    from phoskintime_amd.global_model import NetworkEngine, synthetic
+    net = synthetic.make_network(N=300, total_sites=400, n_K=60, n_tf_edges=700, model=0, seed=77)
+    eng = NetworkEngine(**net)
+    assert eng.N == 300 and eng.S == 1000
+    X = synthetic.random_candidates(net, 8, seed=2)
+    t = np.unique(np.concatenate([net["kin_grid"], [15.0]]))
+    Y, st, _ = eng.simulate_batch(X, t, rtol=1e-7, atol=1e-9)
+    Yd, std, _ = eng.simulate_batch(X[:2], t, rtol=1e-9, atol=1e-11, max_steps=2_000_000, method="dp5")
+    assert not st.cpu().numpy().any() and not std.cpu().numpy().any()
+    a, b = Y[:2].cpu().numpy(), Yd.cpu().numpy()
+    assert np.max(np.abs(a - b) / (1e-8 + 1e-6 * np.abs(b))) <= 0.5
+    eng.close()
