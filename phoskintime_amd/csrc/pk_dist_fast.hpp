@@ -60,8 +60,8 @@ template <int RPL> struct Parked<RPL, true> {
 };
 template <int RPL, bool PARK> constexpr size_t dist_fast_lds_bytes() { return PARK ? (size_t)(3 * RPL + 6) * 256 * sizeof(double) : 0; }
 
-template <int G, int RPL, int METHOD, bool PARK = false>
-__global__ __launch_bounds__(256, PARK ? 2 : 1) void dist_fast_kernel(const SolveArgs A) {
+template <int G, int RPL, int METHOD, bool PARK = false, int MINB = (PARK ? 2 : 1)>
+__global__ __launch_bounds__(256, MINB) void dist_fast_kernel(const SolveArgs A) {
   using Tab = ResolventTab<METHOD>;
   extern __shared__ __align__(16) double park_lds[];
   Parked<RPL, PARK> pk(park_lds);

@@ -46,6 +46,9 @@ if __name__ == '__main__':
             run(1, 14, 65536, meth, 'auto', rtol=rt, atol=at)
             run(2, 4, 65536, meth, 'auto', rtol=rt, atol=at)
             run(2, 5, 65536, meth, 'auto', rtol=rt, atol=at)
+    if which == 'layouts':
+        for n in (4, 8, 10, 12, 14, 16, 18, 20, 24, 28, 30, 32, 40, 48, 56, 62):
+            run(0, n, 65536, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=20)
     if which in ('all', 'rand'):
         for nb in (4, 5, 6):
             run(2, nb, 65536 if nb < 6 else 16384, 'lrp8', 'auto')
