@@ -159,13 +159,13 @@ def main():
                                                                "; 1 RCCL all-gather of Y per step" if use_dist else ""),
                        "replicas_per_gpu": B, "n_states": S, "n_params": P, "n_timepoints": T, "method": args.method,
                        "parallelism": "replica-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": ("pk::dist_fast_kernel<8, 4, %d>" % {"lrp12": 5, "lrp8": 3, "rodas4": 0}[args.method]) if (args.method in ("lrp12", "lrp8", "rodas4") and args.linsolve == "auto") else "see config", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": {"lrp12": "pk::dist_fast_kernel<4, 8, 5, true, 2>", "lrp8": "pk::dist_fast_kernel<8, 4, 3, false, 1>", "rodas4": "pk::dist_fast_kernel<8, 4, 0, false, 1>"}.get(args.method, "see config") if args.linsolve == "auto" else "see config", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_replica": bytes_per_replica,
-                         "note": "path is FP64-VALU/LDS-crossbar bound, not HBM bound (DESIGN.md); HBM fraction reported as the contract asks"},
+                         "note": "path is FP64 VALU-issue bound, not HBM bound (DESIGN.md); HBM fraction reported as the contract asks"},
             "solver": {"mean_accepted_steps": nst[0], "mean_rejected_steps": nst[1], "flagged_replicas": status_bad},
         }
         # HBM traffic of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh)
-        pmc = ROOT / "profiles" / ("r01_h_dist_fast_lrp12_pmc.json" if args.method == "lrp12" else "r01_g_dist_fast_lrp8_pmc.json")
+        pmc = ROOT / "profiles" / ("r01_i_dist_fast_lrp12_parked_pmc.json" if args.method == "lrp12" else "r01_g_dist_fast_lrp8_pmc.json")
         if pmc.exists() and args.method in ("lrp12", "lrp8") and args.linsolve == "auto" and B == 65536 and (args.rtol, args.atol) == ((1e-6, 1e-8) if args.method == "lrp12" else (1e-7, 1e-9)):
             pj = json.loads(pmc.read_text())
             res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
