@@ -1,6 +1,7 @@
 // Instantiations + launcher of the random-model throughput kernel (pk_rand_fast.hpp).
 #include "pk_rand_fast.hpp"
-#include "pk_rand_fast2.hpp"
+#include "pk_rand_fastr.hpp"
+#include <cstring>
 #include <cstdlib>
 #include "pk_launch.hpp"
 
@@ -16,22 +17,28 @@ static void launch_nb(const SolveArgs& a, int method, hipStream_t st) {
   else                          hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
 }
 
+template <int NB, int RPL>
+static void launch_r(const SolveArgs& a, int method, hipStream_t st) {
+  constexpr int G = (1 << NB) / RPL;
+  const long long rpb = 256 / G;
+  const long long nblk = (a.B + rpb - 1) / rpb;
+  if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else                               hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+}
+
 void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {
+  // dev A/B: PK_RAND_ROWS=1 keeps the one-row-per-lane kernels for n = 3, 4
+  static const bool one_row = getenv("PK_RAND_ROWS") && !strcmp(getenv("PK_RAND_ROWS"), "1");
+  if (!one_row && a.n_sites == 3) { launch_r<3, 2>(a, method, st); return; }
+  if (!one_row && a.n_sites == 4) { launch_r<4, 4>(a, method, st); return; }
   switch (a.n_sites) {
     case 1: launch_nb<1>(a, method, st); break;
     case 2: launch_nb<2>(a, method, st); break;
     case 3: launch_nb<3>(a, method, st); break;
     case 4: launch_nb<4>(a, method, st); break;
     case 6: launch_nb<6>(a, method, st); break;            // 64 masks, one wave per replica, v_readlane broadcasts
-    default: {
-      // n = 5: two rows per lane in 16-lane groups (DPP broadcasts); PK_RAND5_G32=1 selects the one-row-per-lane 32-lane kernel (A/B)
-      static const bool g32 = getenv("PK_RAND5_G32") && atoi(getenv("PK_RAND5_G32")) != 0;
-      if (g32) { launch_nb<5>(a, method, st); break; }
-      const long long nblk = (a.B + 15) / 16;
-      if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-      else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-      else                          hipLaunchKernelGGL((rand_fast2_kernel<PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-    } break;
+    default: launch_r<5, 2>(a, method, st); break;      // n = 5: two rows per lane, 16-lane groups (DPP broadcasts; one row per lane: 1.8x slower)
   }
 }
 

@@ -50,8 +50,8 @@ if __name__ == '__main__':
         for n in (4, 8, 10, 12, 14, 16, 18, 20, 24, 28, 30, 32, 40, 48, 56, 62):
             run(0, n, 65536, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=20)
     if which in ('all', 'rand'):
-        for nb in (4, 5, 6):
-            run(2, nb, 65536 if nb < 6 else 16384, 'lrp8', 'auto')
+        for nb in (1, 2, 3, 4, 5, 6):
+            run(2, nb, 65536 if nb < 6 else 16384, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=10)
     if which in ('all', 'c3'):
         run(0, 30, 65536, 'rodas4', 'structured', 0.05, 2.0)
         run(0, 30, 65536, 'bdf2', 'structured')
