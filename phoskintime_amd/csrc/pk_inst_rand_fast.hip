@@ -22,9 +22,10 @@ static void launch_r(const SolveArgs& a, int method, hipStream_t st) {
   constexpr int G = (1 << NB) / RPL;
   const long long rpb = 256 / G;
   const long long nblk = (a.B + rpb - 1) / rpb;
-  if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-  else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-  else                               hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  constexpr size_t lds = rand_fastr_lds_bytes<RPL>();
+  if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  else                               hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), lds, st, a);
 }
 
 void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {

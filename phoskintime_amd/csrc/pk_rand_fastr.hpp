@@ -28,21 +28,28 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
   const double* Dd = th + 4 + n;
   const double cA = th[0], cB = th[1], cC = th[2];
 
+  // Values touched once per step (row coefficients) or once per output (metric bookkeeping) live in LDS, slot-major (slot * 256 + thread:
+  // conflict-free, thread-private, no barrier): the registers belong to the RPL x 2^NB matrix.
+  extern __shared__ __align__(16) double park_lds[];
+  double* const park = park_lds + threadIdx.x;
+  constexpr int K_DG = 0, K_CI = RPL, K_PV = 2 * RPL, K_PR = 3 * RPL, K_M1 = 3 * RPL + 1, K_M2 = 3 * RPL + 2, K_MD = 3 * RPL + 3, K_SH = 3 * RPL + 4;
+  auto ld = [&](int k) { return park[k * 256]; };
+  auto st = [&](int k, double v) { park[k * 256] = v; };
+
   // ---- coefficients of the lane's rows: mask of slot s is l + G * s
-  double dgn[RPL], cin[RPL];
   static_for<RPL>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     const int m = l + G * s;
     if (m == 0) {
       double sumS = 0.0;
       for (int j = 0; j < n; ++j) sumS += Sr[j];
-      dgn[s] = th[3] + sumS; cin[s] = 0.0;
+      st(K_DG + s, th[3] + sumS); st(K_CI + s, 0.0);
     } else {
       const int lsb = __builtin_ctz(m);
-      cin[s] = Sr[lsb];
+      st(K_CI + s, Sr[lsb]);
       double out = 0.0;
       for (int j = 0; j < n; ++j) out += (m & (1 << j)) ? 1.0 : Sr[j < lsb ? j : lsb];
-      dgn[s] = out + Dd[m - 1];
+      st(K_DG + s, out + Dd[m - 1]);
     }
   });
 
@@ -53,8 +60,7 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
 
   // ---- outputs / fused metric.  Observables (sensitivity/analysis.py:90-176): R, P (mask 0) and the masks 1..n
   const int T5 = T > 5 ? T - 5 : 0;
-  double m1 = 0.0, m2 = 0.0, mdyn = 0.0, shift = 0.0, prevR = 0.0, prev[RPL];
-  static_for<RPL>([&](auto sc) { prev[decltype(sc)::value] = 0.0; });
+  static_for<RPL + 5>([&](auto kc) { st(K_PV + decltype(kc)::value, 0.0); });
   auto emit = [&](const int k, const double (&v)[RPL], const double vRaw, const bool nan_fill) {
     auto val = [&](double x, int state) {
       if (nan_fill) return __builtin_nan("");
@@ -85,30 +91,33 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
       const double xr = (l == 0) ? vR : 0.0;
       double loc = xr;
       static_for<RPL>([&](auto sc) { loc += x[decltype(sc)::value]; });
+      double m1 = ld(K_M1), m2 = ld(K_M2), mdyn = ld(K_MD), shift = ld(K_SH), prevR = ld(K_PR);
       if (k == 0) {
         shift = gsum<G>(loc, lane) / (2 + n);
+        st(K_SH, shift);
         prevR = xr;
-        static_for<RPL>([&](auto sc) { constexpr int s = decltype(sc)::value; prev[s] = x[s]; });
+        static_for<RPL>([&](auto sc) { constexpr int s = decltype(sc)::value; st(K_PV + s, x[s]); });
       }
       m1 += loc;
       const double b = (l == 0) ? xr - shift : 0.0;
       m2 = __builtin_fma(b, b, m2);
       const double dr = xr - prevR;
       mdyn = __builtin_fma(dr, dr, mdyn);
-      prevR = xr;
       static_for<RPL>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         const int m = l + G * s;
         const double a = (m <= n) ? x[s] - shift : 0.0;
         m2 = __builtin_fma(a, a, m2);
-        const double d = x[s] - prev[s];
+        const double d = x[s] - ld(K_PV + s);
         mdyn = __builtin_fma(d, d, mdyn);
-        prev[s] = x[s];
+        st(K_PV + s, x[s]);
       });
+      st(K_PR, xr); st(K_M1, m1); st(K_M2, m2); st(K_MD, mdyn);
     }
   };
   auto finish = [&](const int status, const int acc, const int rej) {
     if (A.metric) {
+      const double m1 = ld(K_M1), m2 = ld(K_M2), mdyn = ld(K_MD), shift = ld(K_SH);
       const double L = 2.0 * T + (double)T * n;
       const double tot = gsum<G>(m1, lane);
       double mm;
@@ -145,10 +154,11 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
     static_for<RPL>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       const int m = l + G * s;
-      double a = -dgn[s] * Y[s];
+      const double ci = ld(K_CI + s);
+      double a = -ld(K_DG + s) * Y[s];
       static_for<NB>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const double w = (m & (1 << j)) ? cin[s] : 1.0;
+        const double w = (m & (1 << j)) ? ci : 1.0;
         double nbv;
         if constexpr (j < LG) nbv = xor_partner<(1 << j)>(Y[s]);
         else nbv = Y[s ^ (1 << (j - LG))];
@@ -183,12 +193,13 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
     static_for<RPL>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       const int m = l + G * s;
+      const double ci = ld(K_CI + s), dgs = ld(K_DG + s);
       static_for<NM>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         const int d = m ^ c;
         double v = 0.0;
-        if (d != 0 && (d & (d - 1)) == 0) v = -q * ((m & d) ? cin[s] : 1.0);
-        if (c == m) v = __builtin_fma(q, dgn[s], 1.0);
+        if (d != 0 && (d & (d - 1)) == 0) v = -q * ((m & d) ? ci : 1.0);
+        if (c == m) v = __builtin_fma(q, dgs, 1.0);
         a[s][c] = v;
       });
     });
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
     if (err != err || err > 1e300) {
       ++nrej; after_reject = true; h = 0.1 * hs;
       bool nf = nonfinite(yR) || nonfinite(cA) || nonfinite(cB) || nonfinite(cC);
-      static_for<RPL>([&](auto sc) { constexpr int s = decltype(sc)::value; nf = nf || nonfinite(y[s]) || nonfinite(dgn[s]) || nonfinite(cin[s]); });
+      static_for<RPL>([&](auto sc) { constexpr int s = decltype(sc)::value; nf = nf || nonfinite(y[s]) || nonfinite(ld(K_DG + s)) || nonfinite(ld(K_CI + s)); });
       if (gmax<G>(nf ? 1.0 : 0.0, lane) != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
       continue;
     }
@@ -291,5 +302,7 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
   }
   finish(status, nacc, nrej);
 }
+
+template <int RPL> constexpr size_t rand_fastr_lds_bytes() { return (size_t)(3 * RPL + 5) * 256 * sizeof(double); }
 
 }  // namespace pk
