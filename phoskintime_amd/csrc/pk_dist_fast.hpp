@@ -60,6 +60,20 @@ template <int RPL> struct Parked<RPL, true> {
 };
 template <int RPL, bool PARK> constexpr size_t dist_fast_lds_bytes() { return PARK ? (size_t)(3 * RPL + 6) * 256 * sizeof(double) : 0; }
 
+// pairwise (tree) sum of a lane's RPL values: log2(RPL) dependent adds instead of RPL - 1 (the solve chain is latency-sensitive at
+// two waves per SIMD)
+template <int N>
+__device__ __forceinline__ double tree_sum(const double (&v)[N]) {
+  if constexpr (N == 1) return v[0];
+  else if constexpr (N == 2) return v[0] + v[1];
+  else if constexpr (N == 3) return (v[0] + v[1]) + v[2];
+  else if constexpr (N == 4) return (v[0] + v[1]) + (v[2] + v[3]);
+  else if constexpr (N == 5) return ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
+  else if constexpr (N == 6) return ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+  else if constexpr (N == 7) return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + v[6]);
+  else { static_assert(N == 8, "RPL <= 8"); return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
+}
+
 template <int G, int RPL, int METHOD, bool PARK = false, int MINB = (PARK ? 2 : 1)>
 __global__ __launch_bounds__(256, MINB) void dist_fast_kernel(const SolveArgs A) {
   using Tab = ResolventTab<METHOD>;
@@ -229,24 +243,22 @@ __global__ __launch_bounds__(256, MINB) void dist_fast_kernel(const SolveArgs A)
   auto factor = [&](const double q) {
     qq = q;
     winvR = fast_rcp(__builtin_fma(q, cB, 1.0));
-    double loc = 0.0;
     static_for<RPL>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       winv[j] = fast_rcp(__builtin_fma(q, pk.template get<K_DG + j>(), 1.0));
       cw[j] = q * pk.template get<K_SR + j>() * winv[j];
-      loc += cw[j];
     });
-    Scw = gsum<G>(loc, lane);
+    Scw = gsum<G>(tree_sum(cw), lane);
     sinv = fast_rcp(__builtin_fma(q, Dsum - Scw, 1.0));
   };
   // u = M^{-1} r   (r.sg ignored; u.sg = sum over sites of u): ONE group reduction
   auto solve = [&](const Trk<RPL>& r) {
     Trk<RPL> u;
     const double xR = r.R * winvR;
-    double t[RPL], loc = 0.0;
+    double t[RPL];
 #pragma unroll
-    for (int j = 0; j < RPL; ++j) { t[j] = r.s[j] * winv[j]; loc += t[j]; }
-    const double St = gsum<G>(loc, lane);
+    for (int j = 0; j < RPL; ++j) t[j] = r.s[j] * winv[j];
+    const double St = gsum<G>(tree_sum(t), lane);
     const double xP = __builtin_fma(qq, __builtin_fma(cC, xR, St), r.P) * sinv;
 #pragma unroll
     for (int j = 0; j < RPL; ++j) u.s[j] = __builtin_fma(cw[j], xP, t[j]);
