@@ -147,32 +147,37 @@ __global__ __launch_bounds__(256, MINB) void dist_fast_kernel(const SolveArgs A)
       loc += vs[j];
     }
     if (A.metric) {
-      double m1 = pk.template get<K_M1>(), m2 = pk.template get<K_M2>(), mdyn = pk.template get<K_MD>(), shift = pk.template get<K_SH>();
-      double prevR = pk.template get<K_PR>(), prevP = pk.template get<K_PP>();
-      if (k == 0) {
-        shift = gsum<G>(loc, lane) / (2 + n);
-        pk.template set<K_SH>(shift);
-        prevR = vR; prevP = vP;
-        static_for<RPL>([&](auto jc) { constexpr int j = decltype(jc)::value; pk.template set<K_PS + j>(vs[j]); });
+      // total_signal / mean_activity need the running sum only; the second-moment and first-difference bookkeeping (and its LDS
+      // traffic in the parked layouts) runs only for the metrics that use it -- metric_id is uniform across the launch
+      const bool sum_only = (A.metric_id == PK_METRIC_TOTAL_SIGNAL || A.metric_id == PK_METRIC_MEAN_ACTIVITY);
+      pk.template set<K_M1>(pk.template get<K_M1>() + loc);
+      if (!sum_only) {
+        double m2 = pk.template get<K_M2>(), mdyn = pk.template get<K_MD>(), shift = pk.template get<K_SH>();
+        double prevR = pk.template get<K_PR>(), prevP = pk.template get<K_PP>();
+        if (k == 0) {
+          shift = gsum<G>(loc, lane) / (2 + n);
+          pk.template set<K_SH>(shift);
+          prevR = vR; prevP = vP;
+          static_for<RPL>([&](auto jc) { constexpr int j = decltype(jc)::value; pk.template set<K_PS + j>(vs[j]); });
+        }
+        static_for<RPL>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const int i = l + G * j;
+          const double xs = (i < n) ? vs[j] - shift : 0.0;
+          m2 = __builtin_fma(xs, xs, m2);
+          const double d = vs[j] - pk.template get<K_PS + j>();
+          mdyn = __builtin_fma(d, d, mdyn);
+          pk.template set<K_PS + j>(vs[j]);
+        });
+        if (l == 0) {
+          const double a = vR - shift, b = vP - shift;
+          m2 = __builtin_fma(a, a, m2); m2 = __builtin_fma(b, b, m2);
+          const double dR = vR - prevR, dP = vP - prevP;
+          mdyn = __builtin_fma(dR, dR, mdyn); mdyn = __builtin_fma(dP, dP, mdyn);
+        }
+        pk.template set<K_PR>(vR); pk.template set<K_PP>(vP);
+        pk.template set<K_M2>(m2); pk.template set<K_MD>(mdyn);
       }
-      m1 += loc;
-      static_for<RPL>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const int i = l + G * j;
-        const double xs = (i < n) ? vs[j] - shift : 0.0;
-        m2 = __builtin_fma(xs, xs, m2);
-        const double d = vs[j] - pk.template get<K_PS + j>();
-        mdyn = __builtin_fma(d, d, mdyn);
-        pk.template set<K_PS + j>(vs[j]);
-      });
-      if (l == 0) {
-        const double a = vR - shift, b = vP - shift;
-        m2 = __builtin_fma(a, a, m2); m2 = __builtin_fma(b, b, m2);
-        const double dR = vR - prevR, dP = vP - prevP;
-        mdyn = __builtin_fma(dR, dR, mdyn); mdyn = __builtin_fma(dP, dP, mdyn);
-      }
-      pk.template set<K_PR>(vR); pk.template set<K_PP>(vP);
-      pk.template set<K_M1>(m1); pk.template set<K_M2>(m2); pk.template set<K_MD>(mdyn);
     }
   };
   auto finish = [&](const int status, const int acc, const int rej) {

@@ -91,28 +91,30 @@ __global__ __launch_bounds__(256, 2) void rand_fastr_kernel(const SolveArgs A) {
       const double xr = (l == 0) ? vR : 0.0;
       double loc = xr;
       static_for<RPL>([&](auto sc) { loc += x[decltype(sc)::value]; });
-      double m1 = ld(K_M1), m2 = ld(K_M2), mdyn = ld(K_MD), shift = ld(K_SH), prevR = ld(K_PR);
-      if (k == 0) {
-        shift = gsum<G>(loc, lane) / (2 + n);
-        st(K_SH, shift);
-        prevR = xr;
-        static_for<RPL>([&](auto sc) { constexpr int s = decltype(sc)::value; st(K_PV + s, x[s]); });
+      st(K_M1, ld(K_M1) + loc);
+      if (!(A.metric_id == PK_METRIC_TOTAL_SIGNAL || A.metric_id == PK_METRIC_MEAN_ACTIVITY)) {       // uniform across the launch
+        double m2 = ld(K_M2), mdyn = ld(K_MD), shift = ld(K_SH), prevR = ld(K_PR);
+        if (k == 0) {
+          shift = gsum<G>(loc, lane) / (2 + n);
+          st(K_SH, shift);
+          prevR = xr;
+          static_for<RPL>([&](auto sc) { constexpr int s = decltype(sc)::value; st(K_PV + s, x[s]); });
+        }
+        const double b = (l == 0) ? xr - shift : 0.0;
+        m2 = __builtin_fma(b, b, m2);
+        const double dr = xr - prevR;
+        mdyn = __builtin_fma(dr, dr, mdyn);
+        static_for<RPL>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          const int m = l + G * s;
+          const double a = (m <= n) ? x[s] - shift : 0.0;
+          m2 = __builtin_fma(a, a, m2);
+          const double d = x[s] - ld(K_PV + s);
+          mdyn = __builtin_fma(d, d, mdyn);
+          st(K_PV + s, x[s]);
+        });
+        st(K_PR, xr); st(K_M2, m2); st(K_MD, mdyn);
       }
-      m1 += loc;
-      const double b = (l == 0) ? xr - shift : 0.0;
-      m2 = __builtin_fma(b, b, m2);
-      const double dr = xr - prevR;
-      mdyn = __builtin_fma(dr, dr, mdyn);
-      static_for<RPL>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        const int m = l + G * s;
-        const double a = (m <= n) ? x[s] - shift : 0.0;
-        m2 = __builtin_fma(a, a, m2);
-        const double d = x[s] - ld(K_PV + s);
-        mdyn = __builtin_fma(d, d, mdyn);
-        st(K_PV + s, x[s]);
-      });
-      st(K_PR, xr); st(K_M1, m1); st(K_M2, m2); st(K_MD, mdyn);
     }
   };
   auto finish = [&](const int status, const int acc, const int rej) {
