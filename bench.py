@@ -165,7 +165,7 @@ def main():
             "solver": {"mean_accepted_steps": nst[0], "mean_rejected_steps": nst[1], "flagged_replicas": status_bad},
         }
         # HBM traffic of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh)
-        pmc = ROOT / "profiles" / ("r01_j_dist_fast_lrp12_parked_pmc.json" if args.method == "lrp12" else "r01_g_dist_fast_lrp8_pmc.json")
+        pmc = ROOT / "profiles" / ("r01_k_final_pmc.json" if args.method == "lrp12" else "r01_g_dist_fast_lrp8_pmc.json")
         if pmc.exists() and args.method in ("lrp12", "lrp8") and args.linsolve == "auto" and B == 65536 and (args.rtol, args.atol) == ((1e-6, 1e-8) if args.method == "lrp12" else (1e-7, 1e-9)):
             pj = json.loads(pmc.read_text())
             res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
