@@ -573,3 +573,23 @@ def test_integration_md_binding_stub_runs_as_written(eng, golden_files):
     r = eng.solve_ode_batch(model, g["theta"], g["y0"][0], n, g["t"])
     np.testing.assert_array_equal(sol, _np(r.sol))
     np.testing.assert_array_equal(flat, _np(r.flat))
+
+
+def test_every_layout_of_the_distributive_throughput_kernel(eng):
+    """The default method picks a (lanes x rows-per-lane) layout by n_sites (pk_inst_dist_fast12.hip): one size inside every layout's range,
+    including both ends of each range, against the closed form; fused metric, flat layout and batched y0 included; B not a multiple of the
+    replicas per workgroup."""
+    rng = np.random.default_rng(7)
+    sizes = (1, 4, 5, 8, 9, 12, 13, 16, 17, 20, 21, 24, 25, 28, 29, 32, 33, 40, 41, 48, 49, 56, 57, 62)
+    for n in sizes:
+        P, S = pm.n_params(pm.DIST, n), n + 2
+        B = 37
+        th = rng.uniform(0.0, 20.0, (B, P))
+        y0 = rng.uniform(0.2, 2.0, (B, S))
+        r = eng.solve_ode_batch(pm.DIST, th, y0, n, pm.TIME_POINTS, clip_nonneg=False, metric="variance")
+        assert not _np(r.status).any(), n
+        sol, flat, met = _np(r.sol), _np(r.flat), _np(r.metric)
+        for b in (0, 17, 36):
+            assert pm.band_error(sol[b], pm.solve_exact_lti(pm.DIST, th[b], y0[b], n, pm.TIME_POINTS)) <= 0.1, n
+            np.testing.assert_array_equal(flat[b], pm.flatten_observables(pm.DIST, sol[b], n))
+            np.testing.assert_allclose(met[b], pm.compute_Y(sol[b], n, "variance"), rtol=1e-10)
