@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include "../../include/phoskin.h"
 #include "pk_launch.hpp"
@@ -168,7 +169,16 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   const bool structured = (o.linsolve != PK_LINSOLVE_DENSE) && (model != PK_MODEL_RAND);
   PK_HIP(c, hipSetDevice(c->device));
   dim3 grid((unsigned)nblk);
-  if (model == PK_MODEL_DIST && resolvent_method(o.method) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
+  // small systems, large batches: one lane per replica (64 replicas per wave: the batch must be large enough to occupy the SIMDs).
+  // Thresholds from tools/gpu_bench_dev.py tprB (crossover against the lane-group kernels); PK_TPR=0 / 1 forces the choice (dev A/B).
+  const char* tpr_s = getenv("PK_TPR");
+  const int tpr_env = tpr_s ? atoi(tpr_s) : -1;
+  const long long tpr_min = (model == PK_MODEL_SUCC) ? (n_sites <= 8 ? 16384 : 32768) : (n_sites <= 8 ? 32768 : 49152);
+  const bool tpr = o.method == PK_METHOD_LRP12 && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form && pk::tpr_available(model, n_sites) &&
+                   (tpr_env == 1 || (tpr_env != 0 && B >= tpr_min));
+  if (tpr)
+    pk::launch_tpr(a, model, c->stream);
+  else if (model == PK_MODEL_DIST && resolvent_method(o.method) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
     pk::launch_dist_fast(a, o.method, c->stream);                      // throughput layout: 4-16 lanes per replica, shadowed R / P rows
   else if (rand_fast)
     pk::launch_rand_fast(a, o.method, c->stream);                  // 2^n lanes per replica, shadowed mRNA row

@@ -60,20 +60,6 @@ template <int RPL> struct Parked<RPL, true> {
 };
 template <int RPL, bool PARK> constexpr size_t dist_fast_lds_bytes() { return PARK ? (size_t)(3 * RPL + 6) * 256 * sizeof(double) : 0; }
 
-// pairwise (tree) sum of a lane's RPL values: log2(RPL) dependent adds instead of RPL - 1 (the solve chain is latency-sensitive at
-// two waves per SIMD)
-template <int N>
-__device__ __forceinline__ double tree_sum(const double (&v)[N]) {
-  if constexpr (N == 1) return v[0];
-  else if constexpr (N == 2) return v[0] + v[1];
-  else if constexpr (N == 3) return (v[0] + v[1]) + v[2];
-  else if constexpr (N == 4) return (v[0] + v[1]) + (v[2] + v[3]);
-  else if constexpr (N == 5) return ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
-  else if constexpr (N == 6) return ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
-  else if constexpr (N == 7) return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + v[6]);
-  else { static_assert(N == 8, "RPL <= 8"); return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
-}
-
 template <int G, int RPL, int METHOD, bool PARK = false, int MINB = (PARK ? 2 : 1)>
 __global__ __launch_bounds__(256, MINB) void dist_fast_kernel(const SolveArgs A) {
   using Tab = ResolventTab<METHOD>;

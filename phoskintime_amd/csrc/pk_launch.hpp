@@ -24,6 +24,9 @@ PK_DECL(2, 8) PK_DECL(2, 16) PK_DECL(2, 32) PK_DECL(2, 64)
 void launch_dist_fast(const SolveArgs&, int method, hipStream_t);
 // random-model throughput kernel (pk_rand_fast.hpp): RODAS4 / LRP8, in-register Gauss-Jordan on the 2^n coupled rows
 void launch_rand_fast(const SolveArgs&, int method, hipStream_t);
+// thread-per-replica kernels for small distributive / successive systems (pk_tpr.hpp), LRP12
+bool tpr_available(int model, int n_sites);
+void launch_tpr(const SolveArgs&, int model, hipStream_t);
 void launch_rand_rhs_wide(const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t);
 void launch_rand_jac_wide(const double* theta, double* J, long long B, int n, int S, int P, hipStream_t);
 

@@ -30,6 +30,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 // contracts x - x into fma(a, b, -x), the rounding residual of the product, which is non-zero for finite x.)
 __device__ __forceinline__ bool nonfinite(double x) { return (__double2hiint(x) & 0x7ff00000) == 0x7ff00000; }
 
+// pairwise (tree) sum of a register array: ceil(log2 N) dependent adds instead of N - 1
+template <int LO, int HI, int N>
+__device__ __forceinline__ double tree_sum_range(const double (&v)[N]) {
+  if constexpr (HI - LO == 1) return v[LO];
+  else { constexpr int MID = (LO + HI) / 2; return tree_sum_range<LO, MID>(v) + tree_sum_range<MID, HI>(v); }
+}
+template <int N>
+__device__ __forceinline__ double tree_sum(const double (&v)[N]) { return tree_sum_range<0, N>(v); }
+
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // broadcast lane K of each group to every lane of that group (K compile-time)

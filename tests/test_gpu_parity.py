@@ -593,3 +593,37 @@ def test_every_layout_of_the_distributive_throughput_kernel(eng):
             assert pm.band_error(sol[b], pm.solve_exact_lti(pm.DIST, th[b], y0[b], n, pm.TIME_POINTS)) <= 0.1, n
             np.testing.assert_array_equal(flat[b], pm.flatten_observables(pm.DIST, sol[b], n))
             np.testing.assert_allclose(met[b], pm.compute_Y(sol[b], n, "variance"), rtol=1e-10)
+
+
+def test_thread_per_replica_kernels_agree_with_the_lane_group_kernels(eng, monkeypatch):
+    """Small distributive / successive systems run one replica per lane when the batch is large (pk_tpr.hpp).  Forced on and off with
+    PK_TPR for the same inputs: both paths inside the parity band of the closed form and of each other, same flags, fused metric and flat
+    layout equal; every instantiated size class (NS = 4, 8, 12 / 14) and both ends of each class."""
+    rng = np.random.default_rng(11)
+    for model, sizes in ((pm.DIST, (1, 4, 5, 8, 9, 12)), (pm.SUCC, (1, 2, 4, 5, 8, 9, 14))):
+        for n in sizes:
+            P, S = pm.n_params(model, n), n + 2
+            B = 300                                                    # not a multiple of 256
+            th = rng.uniform(0.0, 20.0, (B, P)); th[3] = 0.0; th[4, 1] = np.nan
+            y0 = rng.uniform(0.2, 2.0, (B, S))
+            res = {}
+            for flag in ("0", "1"):
+                monkeypatch.setenv("PK_TPR", flag)
+                res[flag] = eng.solve_ode_batch(model, th, y0, n, pm.TIME_POINTS, clip_nonneg=False, metric="l2_norm", normalize=(n % 2 == 0))
+            a, b = res["0"], res["1"]
+            np.testing.assert_array_equal(_np(a.status) != 0, _np(b.status) != 0)      # same replicas flagged (the bit may differ: non-finite vs step underflow)
+            assert _np(b.status)[4] != 0 and _np(b.status)[3] == 0 and np.isnan(_np(b.sol)[4, -1]).all()
+            ok = _np(b.status) == 0
+            assert pm.band_error(_np(b.sol)[ok], _np(a.sol)[ok]) <= 0.1, (model, n)
+            np.testing.assert_allclose(_np(b.metric)[ok], _np(a.metric)[ok], rtol=1e-6)
+            np.testing.assert_allclose(_np(b.flat)[ok], _np(a.flat)[ok], rtol=1e-5, atol=1e-8)
+            if n % 2:                                                  # un-normalised: against the closed form
+                for r in (0, 150, 299):
+                    assert pm.band_error(_np(b.sol)[r], pm.solve_exact_lti(model, th[r], y0[r], n, pm.TIME_POINTS)) <= 0.1, (model, n, r)
+    monkeypatch.delenv("PK_TPR")
+    # above the batch threshold the thread-per-replica path is the default: config 1 size (n = 4) at B = 65 536
+    th = rng.uniform(0.0, 20.0, (65536, 12))
+    r = eng.solve_ode_batch(pm.DIST, th, np.ones(6), 4, pm.TIME_POINTS, clip_nonneg=False, want_flat=False)
+    assert not _np(r.status).any()
+    for b in rng.choice(65536, 12, replace=False):
+        assert pm.band_error(_np(r.sol)[b], pm.solve_exact_lti(pm.DIST, th[b], np.ones(6), 4, pm.TIME_POINTS)) <= 0.1

@@ -49,6 +49,23 @@ if __name__ == '__main__':
     if which == 'layouts':
         for n in (4, 8, 10, 12, 14, 16, 18, 20, 24, 28, 30, 32, 40, 48, 56, 62):
             run(0, n, 65536, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=20)
+    if which == 'tprB':
+        import os
+        for model, n in ((0, 4), (0, 12), (1, 4), (1, 14)):
+            for Bx in (1024, 4096, 8192, 16384, 32768):
+                for v in ('0', '1'):
+                    os.environ['PK_TPR'] = v
+                    print('PK_TPR=' + v, end='  ')
+                    run(model, n, Bx, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=20)
+    if which == 'tpr':
+        import os
+        for model, ns in ((0, (1, 4, 8, 12)), (1, (1, 4, 8, 14))):
+            for n in ns:
+                for Bx in (65536, 524288):
+                    for v in ('0', '1'):
+                        os.environ['PK_TPR'] = v
+                        print('PK_TPR=' + v, end='  ')
+                        run(model, n, Bx, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=10)
     if which in ('all', 'rand'):
         for nb in (1, 2, 3, 4, 5, 6):
             run(2, nb, 65536 if nb < 6 else 16384, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=10)
