@@ -173,7 +173,7 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   // Thresholds from tools/gpu_bench_dev.py tprB (crossover against the lane-group kernels); PK_TPR=0 / 1 forces the choice (dev A/B).
   const char* tpr_s = getenv("PK_TPR");
   const int tpr_env = tpr_s ? atoi(tpr_s) : -1;
-  const long long tpr_min = (model == PK_MODEL_SUCC) ? (n_sites <= 8 ? 16384 : 32768) : (n_sites <= 8 ? 32768 : 49152);
+  const long long tpr_min = (model == PK_MODEL_SUCC) ? (n_sites <= 8 ? 16384 : 32768) : (model == PK_MODEL_RAND) ? 32768 : (n_sites <= 8 ? 32768 : 49152);
   const bool tpr = o.method == PK_METHOD_LRP12 && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form && pk::tpr_available(model, n_sites) &&
                    (tpr_env == 1 || (tpr_env != 0 && B >= tpr_min));
   if (tpr)

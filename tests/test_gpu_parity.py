@@ -600,9 +600,9 @@ def test_thread_per_replica_kernels_agree_with_the_lane_group_kernels(eng, monke
     PK_TPR for the same inputs: both paths inside the parity band of the closed form and of each other, same flags, fused metric and flat
     layout equal; every instantiated size class (NS = 4, 8, 12 / 14) and both ends of each class."""
     rng = np.random.default_rng(11)
-    for model, sizes in ((pm.DIST, (1, 4, 5, 8, 9, 12)), (pm.SUCC, (1, 2, 4, 5, 8, 9, 14))):
+    for model, sizes in ((pm.DIST, (1, 4, 5, 8, 9, 12)), (pm.SUCC, (1, 2, 4, 5, 8, 9, 14)), (pm.RAND, (1, 2, 3))):
         for n in sizes:
-            P, S = pm.n_params(model, n), n + 2
+            P, S = pm.n_params(model, n), pm.n_states(model, n)
             B = 300                                                    # not a multiple of 256
             th = rng.uniform(0.0, 20.0, (B, P)); th[3] = 0.0; th[4, 1] = np.nan
             y0 = rng.uniform(0.2, 2.0, (B, S))

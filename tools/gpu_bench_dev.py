@@ -59,7 +59,7 @@ if __name__ == '__main__':
                     run(model, n, Bx, 'lrp12', 'auto', rtol=1e-6, atol=1e-8, iters=20)
     if which == 'tpr':
         import os
-        for model, ns in ((0, (1, 4, 8, 12)), (1, (1, 4, 8, 14))):
+        for model, ns in ((2, (1, 2, 3)),) if len(sys.argv) > 2 and sys.argv[2] == 'rand' else ((0, (1, 4, 8, 12)), (1, (1, 4, 8, 14))):
             for n in ns:
                 for Bx in (65536, 524288):
                     for v in ('0', '1'):
