@@ -79,12 +79,15 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
     to arrays / a scalar; every entry is varied, as in the reference (sensitivity.py:196-215)."""
     params = {k: (np.asarray(fitted_params[k], float) if k != "tf_scale" else float(fitted_params[k])) for k in _ORDER}
     problem = compute_bounds(params, perturbation)
+    design = None
     if param_values is None:
-        param_values = morris.sample(problem, N=trajectories, num_levels=num_levels, seed=seed)
-    X = np.ascontiguousarray(param_values, dtype=np.float64)            # flat vector order == candidate row order (both System.update order)
-    if X.shape[1] != eng.n_var:
-        raise ValueError(f"parameter vector has {X.shape[1]} entries, the network expects {eng.n_var}")
-    total = X.shape[0]
+        # the design is built in HBM from the draws (pk_morris_build_batch): no N (D + 1) x D matrix crosses PCIe on the way in
+        Xd, design = morris.sample_device(problem, N=trajectories, num_levels=num_levels, seed=seed, device=eng.ctx.device)
+    else:
+        Xd = torch.as_tensor(np.ascontiguousarray(param_values, dtype=np.float64), device=torch.device("cuda", eng.ctx.device))
+    if Xd.shape[1] != eng.n_var:                                        # flat vector order == candidate row order (both System.update order)
+        raise ValueError(f"parameter vector has {Xd.shape[1]} entries, the network expects {eng.n_var}")
+    total = Xd.shape[0]
     times = np.unique(np.concatenate([times_p, times_r, times_ph]).astype(np.float64))
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
@@ -93,7 +96,7 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
     n_obs = ld["p_prot"].size + ld["p_rna"].size + ld["p_pho"].size
     try:
         if hi > lo:
-            Y, status, _ = eng.simulate_batch(X[lo:hi], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
+            Y, status, _ = eng.simulate_batch(Xd[lo:hi], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
             pred = eng.observables_batch(lists, Y, n_obs, eps=1e-12)
             yloc = scalar_metric_batch(pred, metric)
             yloc = torch.where(status != 0, torch.zeros_like(yloc), yloc)          # failed simulations contribute Y = 0
@@ -102,9 +105,16 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
             yloc = torch.empty(0, dtype=torch.float64, device=dev); status = torch.empty(0, dtype=torch.int32, device=dev)
         Yall = all_gather_replicas(yloc, total) if world > 1 else yloc
         stat = all_gather_replicas(status, total) if world > 1 else status
+        Yall = torch.nan_to_num(Yall, nan=0.0, posinf=0.0, neginf=0.0)
+        if design is not None:
+            ee = morris.elementary_effects_device(design, Yall).cpu().numpy()      # EE [N, D] on the GPU: 8 N D bytes come back
         torch.cuda.current_stream().synchronize()
     finally:
         eng.free_loss(lists)
-    Yh = np.nan_to_num(Yall.cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0)
-    Si = morris.analyze(problem, X, Yh, num_levels=num_levels, conf_level=conf_level, seed=seed)
+    Yh = Yall.cpu().numpy()
+    X = Xd.cpu().numpy()
+    if design is not None:
+        Si = morris.analyze_effects(ee, problem.get("names"), conf_level=conf_level, seed=seed)
+    else:
+        Si = morris.analyze(problem, X, Yh, num_levels=num_levels, conf_level=conf_level, seed=seed)
     return {"Si": Si, "problem": problem, "param_values": X, "Y": Yh, "status": stat.cpu().numpy()}
