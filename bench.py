@@ -227,6 +227,26 @@ def main():
                 eng.close()
             except Exception as e:  # never let the secondary line break the metric
                 res["network_secondary"] = {"error": repr(e)}
+            # secondary evidence (NOT the metric): the other per-protein configurations BASELINE.json lists, at their sizes
+            try:
+                other = {}
+                for label, mdl, nn, Bo in (("config1_size_distmod_n4_B65536", "distmod", 4, 65536), ("config2_succmod_n14_B4096", "succmod", 14, 4096),
+                                           ("config2_size_succmod_n14_B65536", "succmod", 14, 65536), ("randmod_n4_B65536", "randmod", 4, 65536)):
+                    Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
+                    tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.0, 20.0, (Bo, Po)), device=dev)
+                    oo = batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False)
+                    for _ in range(50):
+                        batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    for _ in range(200):
+                        batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
+                    torch.cuda.synchronize(dev)
+                    dto = (time.perf_counter() - t1) / 200
+                    other[label] = {"replicas_per_s": Bo / dto, "ms": 1e3 * dto, "flagged": int((oo.status != 0).sum())}
+                res["other_protein_configs"] = other
+            except Exception as e:
+                res["other_protein_configs"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
