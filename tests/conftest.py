@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A checkout without the built library (the .so is git-ignored) builds it once before the tests: hipcc is part of the image on the
+    build container and on the GPU box.  This is not a fallback -- the product still refuses to run without its HIP library."""
+    lib = ROOT / "phoskintime_amd" / "libphoskin_hip.so"
+    if not lib.exists():
+        import shutil
+        if shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists():
+            import __graft_entry__ as g
+            g.build()
+
+
 @pytest.fixture(scope="session")
 def golden_files():
     files = sorted((ROOT / "tests" / "golden").glob("protein_*.npz"))
