@@ -51,6 +51,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    # a checkout without the (git-ignored) library: local rank 0 builds it (hipcc is part of the image), the others wait for the file
+    lib_path = ROOT / "phoskintime_amd" / "libphoskin_hip.so"
+    if not lib_path.exists():
+        if local_rank == 0:
+            import __graft_entry__ as graft
+            graft.build()
+        else:
+            last = -1
+            for _ in range(1800):                         # wait until the file exists and has stopped growing
+                size = lib_path.stat().st_size if lib_path.exists() else -1
+                if size > 0 and size == last:
+                    break
+                last = size
+                time.sleep(2.0)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
