@@ -10,7 +10,7 @@
 //     them as wave-uniform-per-group scalars and updates them redundantly, so no broadcast is ever needed;
 //   * the site sum that closes row P is tracked through the stage recurrences (it is linear in the stage vectors), so a
 //     stage costs exactly ONE group reduction (inside the arrow solve), done with DPP moves only;
-//   * no LDS-pipe instruction, no LDS memory, no scratch.
+//   * no LDS-pipe instruction in the solve chain; LDS only as thread-private parking space in the PARK layouts (below).
 //
 // dR/dt = A - B R ; dP/dt = C R - (D + sum S_i) P + sum X_i ; dX_i/dt = S_i P - (1 + D_i) X_i
 #pragma once
