@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PK_VERSION 100
+#define PK_VERSION 200
 
 enum { PK_MODEL_DIST = 0, PK_MODEL_SUCC = 1, PK_MODEL_RAND = 2 };
 
@@ -46,8 +46,9 @@ enum {
 
 /* Linear solver for the implicit stage equations (g I - J) x = r. */
 enum {
-  PK_LINSOLVE_AUTO       = 0, /* fastest available: distmod + RODAS4 -> throughput kernel (4-16 lanes per replica); else structured / dense */
-  PK_LINSOLVE_DENSE      = 1, /* dense in-register LU, one matrix row per lane, cross-lane broadcasts (any model) */
+  PK_LINSOLVE_AUTO       = 0, /* fastest available: resolvent methods (LRP12 / LRP8 / RODAS4) -> the throughput kernels (distmod: 4-16 lanes per
+                                 replica; randmod: bit-mask rows; small systems at large B: one lane per replica); else structured / dense */
+  PK_LINSOLVE_DENSE      = 1, /* dense: in-register Gauss-Jordan to the explicit inverse, one matrix row per lane; every solve is a mat-vec (any model) */
   PK_LINSOLVE_STRUCTURED = 2  /* arrow (distmod) / tridiagonal (succmod) elimination; randmod falls back to dense */
 };
 
@@ -75,7 +76,16 @@ typedef struct pk_solver_opts {
   int32_t normalize;    /* NORMALIZE_MODEL_OUTPUT: sol *= 1 / y0 (distmod.py:116-122)         */
   int32_t stage_form;   /* RODAS4: 0 = resolvent form (1 rhs + 6 solves / step; exact for the affine per-protein models),
                            1 = classical 6-stage Rosenbrock form (same method; kept for nonlinear right-hand sides) */
+  int32_t kernel;       /* PK_KERNEL_*: which kernel family runs a small system.  AUTO picks by batch size (thread-per-replica above a
+                           measured threshold), so the SAME replica can take different roundings / step sequences in batches of
+                           different size -- a sharded run that must reproduce the single-GPU bits pins GROUP or TPR on every rank. */
 } pk_solver_opts;
+
+enum {
+  PK_KERNEL_AUTO  = 0,  /* by batch size (default)                                                             */
+  PK_KERNEL_GROUP = 1,  /* lane-group kernels (several lanes per replica) at every batch size                  */
+  PK_KERNEL_TPR   = 2   /* thread-per-replica kernels wherever one exists for (model, n_sites), else lane-group */
+};
 
 typedef struct pk_ctx pk_ctx;
 

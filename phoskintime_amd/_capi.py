@@ -19,6 +19,8 @@ METHOD_RODAS4, METHOD_BDF2, METHOD_RK4, METHOD_LRP8, METHOD_DP5, METHOD_LRP12 = 
 METHODS = {"rodas4": METHOD_RODAS4, "bdf2": METHOD_BDF2, "rk4": METHOD_RK4, "lrp8": METHOD_LRP8, "dp5": METHOD_DP5, "lrp12": METHOD_LRP12}
 LINSOLVE_AUTO, LINSOLVE_DENSE, LINSOLVE_STRUCTURED = 0, 1, 2
 LINSOLVES = {"auto": LINSOLVE_AUTO, "dense": LINSOLVE_DENSE, "structured": LINSOLVE_STRUCTURED}
+KERNEL_AUTO, KERNEL_GROUP, KERNEL_TPR = 0, 1, 2
+KERNELS = {"auto": KERNEL_AUTO, "group": KERNEL_GROUP, "tpr": KERNEL_TPR}
 METRICS = {"total_signal": 0, "mean_activity": 1, "variance": 2, "dynamics": 3, "l2_norm": 4}
 ST_NONFINITE, ST_MAXSTEPS, ST_HMIN = 1, 2, 4
 
@@ -53,7 +55,7 @@ class SolverOpts(C.Structure):
     """Mirror of ``pk_solver_opts`` (include/phoskin.h)."""
     _fields_ = [("method", C.c_int32), ("linsolve", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double),
                 ("h0", C.c_double), ("rk4_h", C.c_double), ("max_steps", C.c_int32), ("clip_nonneg", C.c_int32),
-                ("normalize", C.c_int32), ("stage_form", C.c_int32)]
+                ("normalize", C.c_int32), ("stage_form", C.c_int32), ("kernel", C.c_int32)]
 
 
 #: every symbol include/phoskin.h declares (tests/test_capi_symbols.py checks the header against this list)
@@ -145,6 +147,8 @@ def default_opts(**kw) -> SolverOpts:
             v = METHODS[v]
         if k == "linsolve" and isinstance(v, str):
             v = LINSOLVES[v]
+        if k == "kernel" and isinstance(v, str):
+            v = KERNELS[v]
         if not hasattr(o, k):
             raise TypeError(f"unknown solver option {k!r}")
         setattr(o, k, v)

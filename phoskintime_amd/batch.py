@@ -87,12 +87,14 @@ def solve_ode_batch(model, theta: ArrayLike, init_cond: ArrayLike, num_psites: i
                     method: Union[str, int, None] = None, linsolve: Union[str, int, None] = None,
                     rtol: Optional[float] = None, atol: Optional[float] = None, h0: Optional[float] = None,
                     rk4_h: Optional[float] = None, max_steps: Optional[int] = None,
-                    clip_nonneg: bool = True, normalize: bool = False, stage_form: int = 0,
+                    clip_nonneg: bool = True, normalize: bool = False, stage_form: int = 0, kernel: Union[str, int, None] = None,
                     device: Optional[int] = None, out: Optional[BatchResult] = None) -> BatchResult:
     """Integrate B replicas of one per-protein model.  ``theta`` is [B, P]; ``init_cond`` [S] (shared) or [B, S].
 
     Asynchronous on torch's current stream.  Semantics per replica are those of the reference's ``solve_ode``
-    (odeint -> clip >= 0 -> optional / y0 -> flat); the integrator is the engine's own (include/phoskin.h)."""
+    (odeint -> clip >= 0 -> optional / y0 -> flat); the integrator is the engine's own (include/phoskin.h).
+    ``kernel`` = "auto" | "group" | "tpr": small systems switch kernel family by batch size under "auto", so a sharded run that must
+    reproduce the single-GPU bits pins one family on every rank."""
     ctx = get_context(device)
     dev = torch.device("cuda", ctx.device)
     mid = model_id(model)
@@ -117,7 +119,7 @@ def solve_ode_batch(model, theta: ArrayLike, init_cond: ArrayLike, num_psites: i
         raise ValueError("t must hold at least one time point")
     F = flat_len(mid, n, T)
     opts = default_opts(method=method, linsolve=linsolve, rtol=rtol, atol=atol, h0=h0, rk4_h=rk4_h, max_steps=max_steps,
-                        clip_nonneg=int(bool(clip_nonneg)), normalize=int(bool(normalize)), stage_form=int(stage_form))
+                        clip_nonneg=int(bool(clip_nonneg)), normalize=int(bool(normalize)), stage_form=int(stage_form), kernel=kernel)
     if out is None:
         out = BatchResult(
             sol=torch.empty((B, T, S), dtype=torch.float64, device=dev) if want_sol else None,

@@ -67,6 +67,7 @@ void pk_default_opts(pk_solver_opts* o) {
   o->max_steps = 100000;
   o->clip_nonneg = 1;
   o->normalize = 0;
+  o->kernel = PK_KERNEL_AUTO;
 }
 
 int pk_protein_n_states(int model, int n_sites) {
@@ -170,14 +171,16 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   PK_HIP(c, hipSetDevice(c->device));
   dim3 grid((unsigned)nblk);
   // small systems, large batches: one lane per replica (64 replicas per wave: the batch must be large enough to occupy the SIMDs).
-  // Thresholds from tools/gpu_bench_dev.py tprB (crossover against the lane-group kernels); PK_TPR=0 / 1 forces the choice (dev A/B).
-  const char* tpr_s = getenv("PK_TPR");
-  const int tpr_env = tpr_s ? atoi(tpr_s) : -1;
+  // Thresholds from tools/gpu_bench_dev.py tprB (crossover against the lane-group kernels).  opts->kernel pins the family (sharded runs
+  // that must reproduce single-GPU bits); the PK_TPR=0 / 1 environment variable (read once per process) does the same for dev A/B runs.
+  static const int tpr_env_once = [] { const char* v = getenv("PK_TPR"); return v ? atoi(v) : -1; }();
+  if (o.kernel < PK_KERNEL_AUTO || o.kernel > PK_KERNEL_TPR) return fail(c, PK_ERR_ARG, "unknown opts->kernel");
+  const int tpr_env = o.kernel == PK_KERNEL_GROUP ? 0 : o.kernel == PK_KERNEL_TPR ? 1 : tpr_env_once;
   const long long tpr_min = (model == PK_MODEL_SUCC) ? (n_sites <= 8 ? 16384 : 32768) : (model == PK_MODEL_RAND) ? 32768 : (n_sites <= 8 ? 32768 : 49152);
   const bool tpr = o.method == PK_METHOD_LRP12 && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form && pk::tpr_available(model, n_sites) &&
                    (tpr_env == 1 || (tpr_env != 0 && B >= tpr_min));
   if (tpr)
-    pk::launch_tpr(a, model, c->stream);
+    PK_HIP(c, pk::launch_tpr(a, model, c->stream));
   else if (model == PK_MODEL_DIST && resolvent_method(o.method) && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form)
     pk::launch_dist_fast(a, o.method, c->stream);                      // throughput layout: 4-16 lanes per replica, shadowed R / P rows
   else if (rand_fast)

@@ -26,7 +26,7 @@ void launch_dist_fast(const SolveArgs&, int method, hipStream_t);
 void launch_rand_fast(const SolveArgs&, int method, hipStream_t);
 // thread-per-replica kernels for small distributive / successive systems (pk_tpr.hpp), LRP12
 bool tpr_available(int model, int n_sites);
-void launch_tpr(const SolveArgs&, int model, hipStream_t);
+hipError_t launch_tpr(const SolveArgs&, int model, hipStream_t);   // sets the dynamic-LDS limit per device; its error is the caller's
 void launch_rand_rhs_wide(const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t);
 void launch_rand_jac_wide(const double* theta, double* J, long long B, int n, int S, int P, hipStream_t);
 

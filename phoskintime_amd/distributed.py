@@ -40,6 +40,46 @@ def all_gather_replicas(local: torch.Tensor, total: int, group: Optional[dist.Pr
     return out[:total]
 
 
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _control_device(group=None) -> torch.device:
+    """Device a control-plane tensor must live on for the group's backend (RCCL moves only HBM tensors)."""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def shared_seed(seed: Optional[int], group: Optional[dist.ProcessGroup] = None) -> Optional[int]:
+    """A seed every rank agrees on.  With ``seed=None`` each rank's ``default_rng(None)`` would draw its OWN Morris design, and
+    the gathered outputs would mix rows of unrelated designs: rank 0 draws 63 bits of OS entropy and broadcasts them (8 bytes, control
+    plane, before the kernel -- the data path keeps its single all-gather).  Single rank or an explicit seed: returned unchanged."""
+    rank, world = _world(group)
+    if seed is not None or world == 1:
+        return seed
+    import numpy as np
+    box = torch.zeros(1, dtype=torch.int64, device=_control_device(group))
+    if rank == 0:
+        box[0] = int(np.random.SeedSequence().entropy % (1 << 62))
+    dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(box.item())
+
+
+def all_gather_with_status(values: torch.Tensor, status: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None):
+    """Per-replica float64 results [n, ...] and their int32 status flags [n] through ONE all-gather: the flags ride as one extra
+    float64 column (exact: they are small integers).  Returns (values [total, ...], status [total] int32)."""
+    width = 1
+    for d in values.shape[1:]:
+        width *= int(d)
+    v2 = values.reshape(values.shape[0], width).to(torch.float64)          # (an empty shard cannot be reshaped with -1)
+    packed = torch.cat([v2, status.to(torch.float64).reshape(-1, 1)], dim=1)
+    full = all_gather_replicas(packed, total, group)
+    return full[:, :-1].reshape((total,) + tuple(values.shape[1:])), full[:, -1].to(torch.int32)
+
+
 def sharded_map(fn: Callable[[int, int], torch.Tensor], total: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """Run ``fn(lo, hi)`` on this rank's shard and all-gather the per-replica results.  ``fn`` returns [hi - lo, ...]."""
     if dist.is_available() and dist.is_initialized():

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from ..sensitivity import morris
-from ..distributed import shard_bounds, all_gather_replicas
+from ..distributed import shard_bounds, all_gather_with_status, shared_seed
 from .engine import NetworkEngine
 
 _ORDER = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i", "tf_scale")
@@ -80,6 +80,7 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
     params = {k: (np.asarray(fitted_params[k], float) if k != "tf_scale" else float(fitted_params[k])) for k in _ORDER}
     problem = compute_bounds(params, perturbation)
     design = None
+    seed = shared_seed(seed)              # N > 1 ranks: every rank must build the SAME design (seed=None would give each its own)
     if param_values is None:
         # the design is built in HBM from the draws (pk_morris_build_batch): no N (D + 1) x D matrix crosses PCIe on the way in
         Xd, design = morris.sample_device(problem, N=trajectories, num_levels=num_levels, seed=seed, device=eng.ctx.device)
@@ -103,8 +104,7 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
         else:
             dev = torch.device("cuda", eng.ctx.device)
             yloc = torch.empty(0, dtype=torch.float64, device=dev); status = torch.empty(0, dtype=torch.int32, device=dev)
-        Yall = all_gather_replicas(yloc, total) if world > 1 else yloc
-        stat = all_gather_replicas(status, total) if world > 1 else status
+        Yall, stat = all_gather_with_status(yloc, status, total) if world > 1 else (yloc, status)      # the ONE collective
         Yall = torch.nan_to_num(Yall, nan=0.0, posinf=0.0, neginf=0.0)
         if design is not None:
             ee = morris.elementary_effects_device(design, Yall).cpu().numpy()      # EE [N, D] on the GPU: 8 N D bytes come back

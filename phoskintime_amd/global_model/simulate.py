@@ -6,6 +6,8 @@ mutations because parameters are packed from the object at call time.  The batch
 ``measure_batch``) are what the optimiser / Morris drivers use."""
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 import pandas as pd
 import torch
@@ -13,16 +15,38 @@ import torch
 from . import config
 from .engine import NetworkEngine
 
+# id(sys) -> (weakref to sys, {model: engine}).  The weak reference is what makes the id trustworthy: an entry is used only while its
+# referent is alive AND identical to the caller's object, and a finalizer closes the engines (frees their HBM) when the System dies, so
+# a recycled id can never hand out a stale topology.
 _engines: dict = {}
 
 
+def _evict(key: int) -> None:
+    ent = _engines.pop(key, None)
+    if ent is not None:
+        for eng in ent[1].values():
+            eng.close()
+
+
 def engine_for(sys, model=None) -> NetworkEngine:
-    """One ``NetworkEngine`` per reference ``System`` (the topology is static; parameters travel per call)."""
+    """One ``NetworkEngine`` per live reference ``System`` and kinetic model (the topology is static; parameters travel per call).
+    Engines are evicted and closed when their ``System`` is garbage-collected."""
     model = config.MODEL if model is None else model
-    key = (id(sys), model)
-    eng = _engines.get(key)
+    key = id(sys)
+    ent = _engines.get(key)
+    if ent is not None and ent[0]() is not sys:                # dead referent whose finalizer has not run yet, or a recycled id
+        _evict(key)
+        ent = None
+    if ent is None:
+        try:
+            ref = weakref.ref(sys)
+        except TypeError as e:                                  # e.g. a __slots__ class without __weakref__
+            raise TypeError("engine_for needs a weak-referenceable System object") from e
+        ent = _engines[key] = (ref, {})
+        weakref.finalize(sys, _evict, key)
+    eng = ent[1].get(model)
     if eng is None:
-        eng = _engines[key] = NetworkEngine.from_system(sys, model)
+        eng = ent[1][model] = NetworkEngine.from_system(sys, model)
     return eng
 
 

@@ -24,5 +24,5 @@ def unpack_params(params, num_psites):
 
 def solve_ode(params, init_cond, num_psites, t):
     """(sol[T, S] clipped >= 0 (and / y0 if NORMALIZE_MODEL_OUTPUT), flat = [R(t5..), P(t0..), sites site-major]).
-    Reference distmod.py:93-134 (odeint at SciPy defaults); here the engine's adaptive RODAS4."""
+    Reference distmod.py:93-134 (odeint at SciPy defaults); here the engine's default integrator: adaptive LRP12 (order-11 L-stable resolvent method, include/phoskin.h) at rtol 1e-6 / atol 1e-8."""
     return solve_host(MODEL_ID, params, init_cond, num_psites, t)

@@ -23,7 +23,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_symbol(built_lib):
     for name in _header_functions():
         assert hasattr(built_lib, name), name
-    assert built_lib.pk_version() == 100
+    assert built_lib.pk_version() == 200
 
 
 def test_shapes(built_lib):
@@ -41,7 +41,7 @@ def test_default_opts_struct_layout(built_lib):
     from phoskintime_amd import _capi
     o = _capi.default_opts()
     assert (o.method, o.linsolve, o.rtol, o.atol, o.max_steps, o.clip_nonneg, o.normalize) == (5, 0, 1e-6, 1e-8, 100000, 1, 0)
-    assert C.sizeof(_capi.SolverOpts) == 56
+    assert C.sizeof(_capi.SolverOpts) == 64          # 2 x i32, 4 x f64, 5 x i32 (+ 4 bytes tail padding)
     o = _capi.default_opts(method="bdf2", linsolve="dense", rtol=1e-9)
     assert (o.method, o.linsolve, o.rtol) == (1, 1, 1e-9)
     with pytest.raises(TypeError):

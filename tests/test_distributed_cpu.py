@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from phoskintime_amd.distributed import shard_bounds, all_gather_replicas, sharded_map
+from phoskintime_amd.distributed import shard_bounds, all_gather_replicas, sharded_map, shared_seed, all_gather_with_status
 
 
 def test_shard_bounds_cover_exactly_once():
@@ -39,6 +39,20 @@ def _worker(rank, world, port, total, q):
         lo, hi = shard_bounds(total, rank, world)
         one = all_gather_replicas(torch.full((hi - lo,), float(rank), dtype=torch.float64), total)
         ok = ok and one.shape == (total,) and float(one.sum()) == float(sum(r * (shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]) for r in range(world)))
+        # values + status flags through one collective
+        vals = torch.arange(lo, hi, dtype=torch.float64) * 0.5
+        flags = torch.tensor([(i % 3) * 2 for i in range(lo, hi)], dtype=torch.int32)
+        v, st = all_gather_with_status(vals, flags, total)
+        ok = ok and torch.equal(v, torch.arange(total, dtype=torch.float64) * 0.5) and st.dtype == torch.int32 \
+            and st.tolist() == [(i % 3) * 2 for i in range(total)]
+        # seed=None must still give every rank the same Morris design (each rank used to draw its own)
+        from phoskintime_amd.sensitivity import morris
+        s = shared_seed(None)
+        d = morris.draw(5, 3, 4, seed=s)
+        sig = torch.tensor([float(s), float(d.base.sum()), float(d.sign.sum()), float((d.rank * [1, 2, 3, 4, 5]).sum())], dtype=torch.float64)
+        both = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(both, sig)
+        ok = ok and all(torch.equal(b, both[0]) for b in both) and shared_seed(17) == 17
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -60,6 +74,9 @@ def test_sharded_map_gloo_world2(total):
 
 
 def test_single_rank_passthrough():
+    assert shared_seed(None) is None and shared_seed(5) == 5
+    v, st = all_gather_with_status(torch.arange(3.0, dtype=torch.float64), torch.tensor([0, 2, 4], dtype=torch.int32), 3)
+    assert v.tolist() == [0.0, 1.0, 2.0] and st.tolist() == [0, 2, 4]
     x = torch.arange(5.0)
     assert all_gather_replicas(x, 5) is x
     assert torch.equal(sharded_map(lambda lo, hi: torch.arange(lo, hi, dtype=torch.float64), 4), torch.arange(4, dtype=torch.float64))

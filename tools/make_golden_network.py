@@ -156,8 +156,93 @@ def main(model_name):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def main_large(model_name):
+    """One N = 100 network per topology at BASELINE config 4 / 5 size: S ~ 500 states, n_K = 40 kinases (20 of them
+    proteins => driven), 250 TF edges, 1-6 sites per protein (combinatorial: 1-3 => 2^ns states).  Slow in pure Python (the finite-
+    difference Dfun alone is S + 1 right-hand sides per refresh); run once:  python tools/make_golden_network.py large [model]
+    Stored: two parameter sets, rhs probes, the VERBATIM simulate_odeint at the optimiser's tolerance (1e-8 / 1e-8, config.toml:403-404)
+    for both and at 1e-12 for the first, the reference's RK45 at its defaults for the first."""
+    import pandas as pd, time
+    mods, tmp = import_reference(model_name)
+    cfg, net, bm, js, sim = mods["config"], mods["network"], mods["buildmat"], mods["jacspeedup"], mods["simulate"]
+    MODEL = cfg.MODEL
+    rng = np.random.default_rng(20260515 + 3 + 100 * MODEL)
+    N, n_ext, n_kp, n_tf = 100, 20, 20, 250
+    max_sites = 3 if MODEL == 2 else 6
+    prots, kinases, inter, tf_net = synth_frames(rng, N, max_sites, n_ext, n_kp, n_tf)
+    idx = net.Index(inter, tf_interactions=tf_net, kin_beta_map={k: float(rng.uniform(0.5, 1.5)) for k in kinases}, tf_beta_map={})
+    grid = np.asarray(cfg.TIME_POINTS_PROTEIN, float)
+    fc_rows = []
+    for k in idx.kinases:
+        base = 1.0 + 0.3 * np.sin(rng.uniform(0, 6) + np.arange(grid.size) * rng.uniform(0.2, 0.8))
+        for t, v in zip(grid, base):
+            fc_rows.append(dict(protein=k, time=float(t), fc=float(max(v, 1e-6))))
+    kin_in = net.KinaseInput(idx.kinases, pd.DataFrame(fc_rows))
+    W = bm.build_W_parallel(inter, idx, n_cores=1)
+    tf_mat = bm.build_tf_matrix(tf_net, idx, tf_beta_map={}, kin_beta_map={})
+    tf_deg = np.asarray(np.abs(tf_mat).sum(axis=1)).ravel().astype(np.float64)
+    tf_deg[tf_deg < 1e-12] = 1.0
+    nK = len(idx.kinases)
+    psets = [dict(c_k=np.ones(nK), A_i=np.ones(idx.N), B_i=np.full(idx.N, 0.2), C_i=np.full(idx.N, 0.5), D_i=np.full(idx.N, 0.05),
+                  Dp_i=np.full(idx.total_sites, 0.05), E_i=np.ones(idx.N), tf_scale=0.1),                       # runner.py:515-524
+             dict(c_k=rng.uniform(0.3, 2.0, nK), A_i=rng.uniform(0.3, 2.0, idx.N), B_i=rng.uniform(0.05, 1.0, idx.N),
+                  C_i=rng.uniform(0.1, 2.0, idx.N), D_i=rng.uniform(0.01, 0.5, idx.N), Dp_i=rng.uniform(0.01, 0.5, idx.total_sites),
+                  E_i=rng.uniform(0.2, 3.0, idx.N), tf_scale=float(rng.uniform(0.1, 4.0)))]
+    K = len(psets)
+    sysm = net.System(idx, W, tf_mat, kin_in, {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in psets[0].items()}, tf_deg)
+    S = idx.state_dim
+    t_eval = np.unique(np.concatenate([cfg.TIME_POINTS_PROTEIN, cfg.TIME_POINTS_RNA, cfg.TIME_POINTS_PHOSPHO])).astype(float)
+    t_probe = np.array([0.0, 0.5, 3.0, 960.0])
+    y0 = sysm.y0()
+    y_rand = rng.uniform(0.0, 2.0, (K, S))
+    rhs_y0 = np.empty((K, t_probe.size, S)); rhs_rand = np.empty((K, t_probe.size, S))
+    Y8 = np.empty((K, t_eval.size, S)); Ytight = np.empty((1, t_eval.size, S)); Yrk = np.empty((1, t_eval.size, S))
+    print(model_name, "large: N", idx.N, "S", S, "n_K", nK, "sites", idx.total_sites, flush=True)
+    for k, ps in enumerate(psets):
+        sysm.update(**ps)
+        if MODEL == 2:
+            js.build_S_cache_into(sysm.S_cache, sysm.W_indptr, sysm.W_indices, sysm.W_data, sysm.kin_Kmat, sysm.c_k)
+            args = sysm.odeint_args(sysm.S_cache)
+        else:
+            args = sysm.odeint_args()
+        for ti, t in enumerate(t_probe):
+            rhs_y0[k, ti] = js.rhs_odeint(y0.copy(), float(t), *args)
+            rhs_rand[k, ti] = js.rhs_odeint(y_rand[k].copy(), float(t), *args)
+        t0 = time.time()
+        Y8[k] = sim.simulate_odeint(sysm, t_eval, 1e-8, 1e-8, 200000)
+        print(model_name, "large set", k, "LSODA 1e-8 done in", round(time.time() - t0), "s", flush=True)
+        if k == 0:
+            t0 = time.time()
+            Yrk[0] = js.solve_custom(sysm, y0.copy(), t_eval, 1e-5, 1e-7)
+            print(model_name, "large RK45 done in", round(time.time() - t0), "s", flush=True)
+            t0 = time.time()
+            Ytight[0] = sim.simulate_odeint(sysm, t_eval, 1e-12, 1e-12, 500000)
+            print(model_name, "large LSODA 1e-12 done in", round(time.time() - t0), "s", flush=True)
+    driver_map = np.asarray(sysm.odeint_args(sysm.S_cache)[-3] if MODEL == 2 else sysm.odeint_args()[-1], dtype=np.int32)
+    d = dict(model=MODEL, N=idx.N, n_K=nK, total_sites=idx.total_sites, S=S, offset_y=idx.offset_y, offset_s=idx.offset_s, n_sites=idx.n_sites,
+             W_indptr=sysm.W_indptr, W_indices=sysm.W_indices, W_data=sysm.W_data, n_W_rows=sysm.n_W_rows,
+             TF_indptr=sysm.TF_indptr, TF_indices=sysm.TF_indices, TF_data=sysm.TF_data, tf_deg=sysm.tf_deg,
+             driver_map=driver_map, kin_grid=sysm.kin_grid, kin_Kmat=sysm.kin_Kmat,
+             t_eval=t_eval, t_probe=t_probe, y0=y0, y_rand=y_rand, rhs_y0=rhs_y0, rhs_rand=rhs_rand,
+             Y_lsoda8=Y8, Y_tight=Ytight, Y_rk45=Yrk,
+             c_k=np.stack([p["c_k"] for p in psets]), A_i=np.stack([p["A_i"] for p in psets]), B_i=np.stack([p["B_i"] for p in psets]),
+             C_i=np.stack([p["C_i"] for p in psets]), D_i=np.stack([p["D_i"] for p in psets]), Dp_i=np.stack([p["Dp_i"] for p in psets]),
+             E_i=np.stack([p["E_i"] for p in psets]), tf_scale=np.array([p["tf_scale"] for p in psets]))
+    if MODEL == 2:
+        d.update(n_states=idx.n_states, trans_from=sysm.trans_from, trans_to=sysm.trans_to, trans_site=sysm.trans_site,
+                 trans_off=sysm.trans_off, trans_n=sysm.trans_n)
+    np.savez_compressed(OUT / f"netlarge_m{MODEL}.npz", **d)
+    print("wrote netlarge", model_name, flush=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "large":
+        if len(sys.argv) > 2:
+            main_large(sys.argv[2]); sys.exit(0)
+        procs = [subprocess.Popen([sys.executable, __file__, "large", m]) for m in MODEL_ID]
+        sys.exit(max(p.wait() for p in procs))
     if which == "all":
         procs = [subprocess.Popen([sys.executable, __file__, m]) for m in MODEL_ID]
         sys.exit(max(p.wait() for p in procs))
