@@ -466,3 +466,165 @@ def frechet_distance(true_coords, pred_coords) -> float:
         for j in range(1, m):
             c[i, j] = max(min(c[i - 1, j], c[i, j - 1], c[i - 1, j - 1]), d[i, j])
     return float(c[-1, -1])
+
+
+# ------------------------------------------------------------------------------------------ decision vector (global_model/params.py)
+PARAM_KEYS = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i")
+BOUNDS_CONFIG = {"c_k": (1e-3, 4.0), "A_i": (1e-6, 10.0), "B_i": (1e-3, 1.0), "C_i": (1e-3, 2.0), "D_i": (0.1, 0.5), "Dp_i": (0.05, 5.0),
+                 "E_i": (1e-4, 10.0), "tf_scale": (2.0, 10.0)}                       # config.toml:368-397
+
+
+def softplus(x):
+    """global_model/utils.py:229-241, element by element."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    for i in range(x.size):
+        xi = x.flat[i]
+        out.flat[i] = xi if xi > 20.0 else np.log1p(np.exp(xi))
+    return out
+
+
+def inv_softplus(y):
+    """global_model/utils.py:244-253."""
+    y = np.asarray(y, dtype=np.float64)
+    out = np.empty_like(y)
+    for i in range(y.size):
+        yi = y.flat[i]
+        if yi < 1e-12:
+            yi = 1e-12
+        out.flat[i] = np.log(np.expm1(yi))
+    return out
+
+
+def init_raw_params(defaults: dict, custom_bounds: Optional[dict] = None):
+    """global_model/params.py:24-103: (theta0, slices, xl, xu) in raw space, groups in PARAM_KEYS order then tf_scale."""
+    custom_bounds = custom_bounds or {}
+    vecs, slices, bounds, curr = [], {}, [], 0
+    for k in PARAM_KEYS:
+        raw = inv_softplus(defaults[k])
+        vecs.append(raw)
+        slices[k] = slice(curr, curr + len(raw)); curr += len(raw)
+        pmin, pmax = custom_bounds[k] if k in custom_bounds else BOUNDS_CONFIG[k]
+        bounds.extend([(inv_softplus(np.array([pmin]))[0], inv_softplus(np.array([pmax]))[0])] * len(raw))
+    vecs.append(inv_softplus(np.array([defaults["tf_scale"]])))
+    slices["tf_scale"] = slice(curr, curr + 1)
+    pmin, pmax = custom_bounds["tf_scale"] if "tf_scale" in custom_bounds else BOUNDS_CONFIG["tf_scale"]
+    bounds.append((inv_softplus(np.array([pmin]))[0], inv_softplus(np.array([pmax]))[0]))
+    return np.concatenate(vecs), slices, np.array([b[0] for b in bounds], float), np.array([b[1] for b in bounds], float)
+
+
+def unpack_params(theta, slices) -> Params:
+    """global_model/params.py:106-132."""
+    theta = np.asarray(theta, float)
+    return Params(*(softplus(theta[slices[k]]) for k in PARAM_KEYS), float(softplus(theta[slices["tf_scale"]])[0]))
+
+
+def params_to_row(p: Params) -> np.ndarray:
+    return np.concatenate([np.ravel(getattr(p, k)) for k in PARAM_KEYS] + [[p.tf_scale]])
+
+
+# ------------------------------------------------------------------------------------------ observables (global_model/simulate.py:83-202)
+def simulate_and_measure(net: Network, p: Params, t_points_p, t_points_r, t_points_pho, y0=None, rtol=1e-5, atol=1e-7, mxstep=5000):
+    """The three pred_fc frames of simulate_and_measure as arrays, rows in the reference's order (protein-major, then [site,] time):
+    one LSODA solve at rtol 1e-5 / atol 1e-7, mxstep 5000 on the union grid, fold change against t = 0 (protein, phospho) / t = 4 (RNA)
+    with the 1e-12 floors, rows kept where the time is in the modality's list.
+    Returns dict(p_i, p_t, p_fc, r_i, r_t, r_fc, ph_i, ph_s, ph_t, ph_fc)."""
+    times = np.unique(np.concatenate([t_points_p, t_points_r, t_points_pho]).astype(np.float64))
+    Y = simulate_odeint(net, p, times, rtol, atol, mxstep, y0=y0)          # defaults = the reference's hard-wired values (simulate.py:110)
+    bidx = lambda t0: int(np.argmin(np.abs(times - float(t0))))
+    pb, rb, phb = bidx(0.0), bidx(4.0), bidx(0.0)
+    keep_p, keep_r, keep_ph = (np.isin(times, np.asarray(x, float)) for x in (t_points_p, t_points_r, t_points_pho))
+    out = {k: [] for k in ("p_i", "p_t", "p_fc", "r_i", "r_t", "r_fc", "ph_i", "ph_s", "ph_t", "ph_fc")}
+    for i in range(net.N):
+        st = int(net.offset_y[i])
+        R = Y[:, st]
+        fc_r = np.maximum(R, 1e-12) / np.maximum(R[rb], 1e-12)
+        out["r_i"].append(np.full(keep_r.sum(), i)); out["r_t"].append(times[keep_r]); out["r_fc"].append(fc_r[keep_r])
+        ns = int(net.n_sites[i])
+        if net.model == 2:
+            cnt = int(net.n_states[i]) if net.n_states is not None else (1 << ns)
+            states = Y[:, st + 1: st + 1 + cnt]
+            tot = states.sum(axis=1)
+            if ns > 0:
+                m = np.arange(cnt, dtype=np.uint32)[:, None]; j = np.arange(ns, dtype=np.uint32)[None, :]
+                sites = states @ ((m >> j) & 1).astype(np.float64)
+            else:
+                sites = None
+        else:
+            P0 = Y[:, st + 1]
+            sites = Y[:, st + 2: st + 2 + ns] if ns > 0 else None
+            tot = P0 + (sites.sum(axis=1) if ns > 0 else np.zeros_like(P0))
+        fc_p = np.maximum(tot, 1e-12) / np.maximum(tot[pb], 1e-12)
+        out["p_i"].append(np.full(keep_p.sum(), i)); out["p_t"].append(times[keep_p]); out["p_fc"].append(fc_p[keep_p])
+        if sites is not None:
+            for s in range(ns):
+                sig = sites[:, s]
+                fc = np.maximum(sig, 1e-12) / np.maximum(sig[phb], 1e-12)
+                out["ph_i"].append(np.full(keep_ph.sum(), i)); out["ph_s"].append(np.full(keep_ph.sum(), s))
+                out["ph_t"].append(times[keep_ph]); out["ph_fc"].append(fc[keep_ph])
+    cat = lambda v, dt: (np.concatenate(v).astype(dt) if v else np.zeros(0, dt))
+    return {k: cat(v, np.int32 if k.endswith("_i") or k.endswith("_s") else np.float64) for k, v in out.items()}
+
+
+# ------------------------------------------------------------------------------------------ network Morris helpers (global_model/sensitivity.py)
+def compute_bounds(params_dict: dict, perturbation: float = 0.05):
+    """global_model/sensitivity.py:41-80 (default perturbation = config.toml:351 sensitivity_perturbation)."""
+    bounds, names = [], []
+    for key, value in params_dict.items():
+        if isinstance(value, np.ndarray):
+            for i, v in enumerate(value):
+                lb = v * (1 - perturbation); ub = v * (1 + perturbation)
+                if abs(v) < 1e-6:
+                    lb, ub = 0.0, 0.01
+                bounds.append([max(0.0, lb), ub]); names.append(f"{key}_{i}")
+        else:
+            v = float(value)
+            lb = v * (1 - perturbation); ub = v * (1 + perturbation)
+            if abs(v) < 1e-6:
+                lb, ub = 0.0, 0.01
+            bounds.append([max(0.0, lb), ub]); names.append(key)
+    return {"num_vars": len(names), "names": names, "bounds": bounds}
+
+
+def reconstruct_params(param_vector, original_shapes: dict) -> dict:
+    """global_model/sensitivity.py:83-103."""
+    out, curr = {}, 0
+    for key, shape in original_shapes.items():
+        if shape == ():
+            out[key] = param_vector[curr]; curr += 1
+        else:
+            size = int(np.prod(shape))
+            out[key] = np.array(param_vector[curr: curr + size]); curr += size
+    return out
+
+
+def compute_scalar_metric(v_prot, v_rna, v_pho, metric: str = "total_signal") -> float:
+    """global_model/sensitivity.py:106-140 on the pred_fc columns (protein, rna, phospho order)."""
+    combined = np.concatenate([np.asarray(v_prot, float), np.asarray(v_rna, float), np.asarray(v_pho, float)])
+    if len(combined) == 0:
+        return 0.0
+    if metric == "total_signal":
+        return float(np.sum(combined))
+    if metric == "mean":
+        return float(np.mean(combined))
+    if metric == "variance":
+        return float(np.var(combined))
+    if metric == "l2_norm":
+        return float(np.linalg.norm(combined))
+    return float(np.sum(combined))
+
+
+# ------------------------------------------------------------------------------------------ one optimiser candidate (global_model/optproblem.py:87-160)
+def evaluate(net: Network, x_raw, slices, defaults_row, ld: dict, mode: int, lambdas: dict, time_grid, fail_value: float = 1e12,
+             rtol: float = 1e-8, atol: float = 1e-8, mxstep: int = 200000):
+    """GlobalODE_MOO._evaluate: unpack (softplus) -> prior penalty -> simulate_odeint at the optimiser's tolerances -> LOSS_FN ->
+    the three objectives; fail_value when the trajectory is not finite."""
+    p = unpack_params(x_raw, slices)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            Y = simulate_odeint(net, p, np.asarray(time_grid, float), rtol, atol, mxstep)
+        except Exception:
+            Y = None
+    return objectives(net, params_to_row(p), np.asarray(defaults_row, float), Y, ld, mode, lambdas, fail_value)

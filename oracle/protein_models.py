@@ -304,23 +304,49 @@ def solve_exact_lti(model: int, params, init_cond, n_sites: int, t):
 
 # --------------------------------------------------------------------- reductions
 def compute_Y(solution: np.ndarray, n_sites: int, metric: str = "total_signal") -> float:
-    """sensitivity/analysis.py:90-176 (_compute_Y) with Y_METRIC as an argument."""
+    """sensitivity/analysis.py:90-176 (_compute_Y) with Y_METRIC as an argument -- loop for loop, in the reference's summation order
+    (pinned bit for bit by tests/golden/pins_protein.npz)."""
     sol = np.asarray(solution, dtype=float)
     n_t = sol.shape[0]
     length = 2 * n_t + n_t * n_sites
-    sub = sol[:, :2 + n_sites]
-    total = float(sub[:, 0].sum() + sub[:, 1].sum() + sub[:, 2:].sum())
+    sum_m = 0.0; sum_p = 0.0; sum_s = 0.0
+    for t in range(n_t):
+        sum_m += sol[t, 0]
+        sum_p += sol[t, 1]
+        for s in range(n_sites):
+            sum_s += sol[t, 2 + s]
     if metric == "total_signal":
-        return total
+        return float(sum_m + sum_p + sum_s)
     if metric == "mean_activity":
-        return total / length
+        return float((sum_m + sum_p + sum_s) / length)
     if metric == "variance":
-        mean = total / length
-        return float(((sub - mean) ** 2).sum() / length)
+        mean = (sum_m + sum_p + sum_s) / length
+        acc = 0.0
+        for t in range(n_t):
+            acc += (sol[t, 0] - mean) ** 2
+            acc += (sol[t, 1] - mean) ** 2
+            for s in range(n_sites):
+                acc += (sol[t, 2 + s] - mean) ** 2
+        return float(acc / length)
     if metric == "dynamics":
-        return float((np.diff(sub, axis=0) ** 2).sum())
+        acc = 0.0
+        for col in range(2 + n_sites):                   # mRNA chain, protein chain, then the site chains in sequence
+            prev = sol[0, col]
+            for t in range(1, n_t):
+                cur = sol[t, col]
+                acc += (cur - prev) ** 2
+                prev = cur
+        return float(acc)
     if metric == "l2_norm":
-        return float(math.sqrt((sub ** 2).sum()))
+        acc = 0.0
+        for t in range(n_t):
+            acc += sol[t, 0] ** 2
+        for t in range(n_t):
+            acc += sol[t, 1] ** 2
+        for t in range(n_t):
+            for s in range(n_sites):
+                acc += sol[t, 2 + s] ** 2
+        return float(math.sqrt(acc))
     raise ValueError("Unknown Y_METRIC")
 
 
@@ -339,6 +365,42 @@ def score_fit(params, target, prediction, alpha=1.0, beta=1.0, gamma=1.0, delta=
     variance = np.var(residual)
     l2 = np.linalg.norm(params, ord=2) / len(params)
     return delta * mse + alpha * rmse + beta * mae + gamma * variance + mu * l2
+
+
+def define_sensitivity_problem(model: int, n_sites: int, values, perturbation: float = 0.5):
+    """sensitivity/analysis.py:38-87 (define_sensitivity_problem_ds / _rand): names A..D, S1..Sn, D1..Dm and compute_bound per value."""
+    names = ["A", "B", "C", "D"] + [f"S{i + 1}" for i in range(n_sites)]
+    if model == RAND:                    # config/helpers/__init__.py:5-22: one D per non-empty site subset, by size then lexicographic
+        from itertools import combinations
+        for i in range(1, n_sites + 1):
+            for combo in combinations(range(1, n_sites + 1), i):
+                names.append("D" + "".join(map(str, combo)))
+    else:
+        names += [f"D{i + 1}" for i in range(n_sites)]
+    assert len(values) == len(names), "Length mismatch with values"
+    return {"num_vars": len(names), "names": names, "bounds": [compute_bound(v, perturbation) for v in values]}
+
+
+def multistart_start_list(gene: str, base_p0, lb, ub, n_starts: int = 24, jitter_frac: float = 0.10, seed: int = 42):
+    """paramest/normest.py:217-265: the candidate start points of _curve_fit_multistart, draw for draw."""
+    lb = np.asarray(lb, float); ub = np.asarray(ub, float)
+    rng = np.random.default_rng(int(seed + (sum(ord(c) for c in str(gene)) % 1000003)))
+    base = np.clip(np.asarray(base_p0, float).copy(), lb, ub)
+    out = [base]
+    span = ub - lb
+    span[span <= 0] = 1.0
+    for _ in range(max(0, n_starts // 3)):
+        noise = rng.normal(0.0, 1.0, size=base.shape[0])
+        out.append(np.clip(base + (jitter_frac * span) * noise, lb, ub))
+    remaining = max(0, n_starts - len(out))
+    if remaining > 0:
+        U = np.empty((remaining, base.shape[0]))
+        for j in range(base.shape[0]):
+            u = (np.arange(remaining) + rng.random(remaining)) / float(remaining)
+            rng.shuffle(u)
+            U[:, j] = u
+        out.extend(list(lb + U * (ub - lb)))
+    return np.stack(out)
 
 
 def compute_bound(value: float, perturbation: float = 0.5):

@@ -43,18 +43,27 @@ class NetworkEngine:
         self.n_var = self.ctx.lib.pk_network_n_var(self._h)
 
     # ------------------------------------------------------------------ constructors from reference objects
+    @staticmethod
+    def desc_from_system(sys) -> dict:
+        """Host-only packing of a reference ``global_model.network.System`` (duck-typed: only its array attributes and the index maps
+        are read) into the constructor's keyword arrays.  ``driver_map`` follows network.py:454-469: a kinase that is also a protein
+        drives that protein's block; an orphan TF is driven by its proxy kinase (``idx.p2i`` already redirects the orphan)."""
+        idx = sys.idx
+        drv = np.full(idx.N, -1, dtype=np.int32)
+        for k_name in idx.kinases:
+            if k_name in idx.p2i:
+                drv[idx.p2i[k_name]] = idx.k2i[k_name]
+        for orphan, proxy in getattr(idx, "proxy_map", {}).items():
+            if orphan in idx.p2i:
+                drv[idx.p2i[orphan]] = idx.k2i[proxy]
+        return dict(offset_y=_i32(idx.offset_y), offset_s=_i32(idx.offset_s), n_sites=_i32(idx.n_sites), W_indptr=_i32(sys.W_indptr),
+                    W_indices=_i32(sys.W_indices), W_data=_f64(sys.W_data), TF_indptr=_i32(sys.TF_indptr), TF_indices=_i32(sys.TF_indices),
+                    TF_data=_f64(sys.TF_data), tf_deg=_f64(sys.tf_deg), driver_map=drv, kin_grid=_f64(sys.kin_grid), kin_Kmat=_f64(sys.kin_Kmat))
+
     @classmethod
     def from_system(cls, sys, model: int, device: Optional[int] = None):
-        """From a reference ``global_model.network.System`` (duck-typed: only its array attributes are read)."""
-        drv = np.full(sys.idx.N, -1, dtype=np.int32)                 # network.py:454-469
-        for k_name in sys.idx.kinases:
-            if k_name in sys.idx.p2i:
-                drv[sys.idx.p2i[k_name]] = sys.idx.k2i[k_name]
-        for orphan, proxy in getattr(sys.idx, "proxy_map", {}).items():
-            if orphan in sys.idx.p2i:
-                drv[sys.idx.p2i[orphan]] = sys.idx.k2i[proxy]
-        return cls(model, sys.idx.offset_y, sys.idx.offset_s, sys.idx.n_sites, sys.W_indptr, sys.W_indices, sys.W_data,
-                   sys.TF_indptr, sys.TF_indices, sys.TF_data, sys.tf_deg, drv, sys.kin_grid, sys.kin_Kmat, device)
+        """From a reference ``global_model.network.System`` (``desc_from_system`` + upload)."""
+        return cls(model, device=device, **cls.desc_from_system(sys))
 
     @classmethod
     def from_odeint_args(cls, args: Sequence, model: int, device: Optional[int] = None):

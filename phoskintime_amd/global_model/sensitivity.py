@@ -13,12 +13,13 @@ import torch
 
 from ..sensitivity import morris
 from ..distributed import shard_bounds, all_gather_with_status, shared_seed
+from . import config
 from .engine import NetworkEngine
 
 _ORDER = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i", "tf_scale")
 
 
-def compute_bounds(params_dict, perturbation=0.2):
+def compute_bounds(params_dict, perturbation=config.SENSITIVITY_PERTURBATION):
     bounds, names = [], []
     for key, value in params_dict.items():
         if isinstance(value, np.ndarray):
@@ -72,8 +73,9 @@ def scalar_metric_batch(pred: torch.Tensor, metric: str = "total_signal") -> tor
     return pred.sum(dim=1)
 
 
-def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, times_r, times_ph, perturbation: float = 0.05,
-                          trajectories: int = 100, num_levels: int = 40, metric: str = "total_signal", seed: Optional[int] = None,
+def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, times_r, times_ph, perturbation: float = config.SENSITIVITY_PERTURBATION,
+                          trajectories: int = config.SENSITIVITY_TRAJECTORIES, num_levels: int = config.SENSITIVITY_LEVELS,
+                          metric: str = config.SENSITIVITY_METRIC, seed: Optional[int] = None,
                           param_values: Optional[np.ndarray] = None, y0=None, conf_level: float = 0.95, rtol: float = 1e-5, atol: float = 1e-7):
     """Returns dict(Si, problem, param_values, Y, status).  ``fitted_params`` maps the eight parameter groups (System.update order)
     to arrays / a scalar; every entry is varied, as in the reference (sensitivity.py:196-215)."""

@@ -32,17 +32,28 @@ def engine_for(sys, model=None) -> NetworkEngine:
     """One ``NetworkEngine`` per live reference ``System`` and kinetic model (the topology is static; parameters travel per call).
     Engines are evicted and closed when their ``System`` is garbage-collected."""
     model = config.MODEL if model is None else model
+    try:
+        weakref.ref(sys)
+        weak = True
+    except TypeError:
+        weak = False
+    if not weak:
+        # duck-typed stand-ins that cannot be weakly referenced (e.g. types.SimpleNamespace): the engines live ON the object, so their
+        # lifetime is the object's and no id is ever involved
+        store = getattr(sys, "__dict__", None)
+        if store is None:
+            raise TypeError("engine_for needs a System object that is weak-referenceable or has a __dict__")
+        cache = store.setdefault("_pk_engines", {})
+        if model not in cache:
+            cache[model] = NetworkEngine.from_system(sys, model)
+        return cache[model]
     key = id(sys)
     ent = _engines.get(key)
     if ent is not None and ent[0]() is not sys:                # dead referent whose finalizer has not run yet, or a recycled id
         _evict(key)
         ent = None
     if ent is None:
-        try:
-            ref = weakref.ref(sys)
-        except TypeError as e:                                  # e.g. a __slots__ class without __weakref__
-            raise TypeError("engine_for needs a weak-referenceable System object") from e
-        ent = _engines[key] = (ref, {})
+        ent = _engines[key] = (weakref.ref(sys), {})
         weakref.finalize(sys, _evict, key)
     eng = ent[1].get(model)
     if eng is None:

@@ -28,8 +28,14 @@ def compute_bound(value, perturbation=None):
 
 
 def _rand_param_names(num_psites: int):
-    m = (1 << num_psites) - 1
-    return ['A', 'B', 'C', 'D'] + [f'S{i + 1}' for i in range(num_psites)] + [f'D{i + 1}' for i in range(m)]
+    """config/helpers/__init__.py:5-22 (get_param_names_rand): D12 = joint dephosphorylation of sites 1 and 2; subsets by size, then
+    lexicographic -- the order of the D block of randmod's parameter vector."""
+    from itertools import combinations
+    names = ['A', 'B', 'C', 'D'] + [f'S{i}' for i in range(1, num_psites + 1)]
+    for i in range(1, num_psites + 1):
+        for combo in combinations(range(1, num_psites + 1), i):
+            names.append(f"D{''.join(map(str, combo))}")
+    return names
 
 
 def define_sensitivity_problem_rand(num_psites, values):

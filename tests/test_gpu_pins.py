@@ -1,0 +1,96 @@
+"""GPU: the HIP path against the reference-run pins (tools/make_golden_pins.py) for the rows VERDICT r1 listed as "restated only":
+a18 simulate_and_measure, a21 unpack_params, a22 GlobalODE_MOO._evaluate, a24 the network Morris helpers' inputs."""
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import network_models as nm
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+NETPINS = sorted(GOLD.glob("pins_network_m*.npz"))
+KEYS = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i", "tf_scale")
+
+
+def _slices(g):
+    return {k: slice(int(a), int(b)) for k, (a, b) in zip(KEYS, g["slice_bounds"])}
+
+
+def _system(g, x_phys):
+    """Attribute surface of the reference's System / Index (network.py:28-526) from a pins file; names are the reference's own."""
+    N = int(g["N"]); ns = g["n_sites"]
+    prots = [str(p) for p in g["proteins"]]
+    names = [str(s) for s in g["site_names"]]
+    sites, o = [], 0
+    for i in range(N):
+        sites.append(names[o:o + int(ns[i])]); o += int(ns[i])
+    sl = _slices(g)
+    idx = SimpleNamespace(N=N, proteins=prots, sites=sites, offset_y=g["offset_y"], offset_s=g["offset_s"], n_sites=ns)
+    vals = {k: (x_phys[sl[k]].copy() if k != "tf_scale" else float(x_phys[sl[k]][0])) for k in KEYS}
+    return SimpleNamespace(idx=idx, y0=lambda: g["y0"].copy(), _pk_engines={}, **vals), idx
+
+
+@pytest.mark.parametrize("f", NETPINS, ids=lambda f: f.stem)
+def test_softplus_unpack_matches_reference_unpack_params(f):
+    from phoskintime_amd.global_model import NetworkEngine
+    g = np.load(f)
+    eng = NetworkEngine.from_npz(g)
+    assert eng.n_var == g["X_raw"].shape[1]
+    np.testing.assert_allclose(eng.unpack_batch(g["X_raw"]).cpu().numpy(), g["X_phys"], rtol=2e-16, atol=0)
+    eng.close()
+
+
+@pytest.mark.parametrize("f", NETPINS, ids=lambda f: f.stem)
+def test_simulate_and_measure_frames_against_the_reference_frames(f):
+    """The drop-in returns the reference's frames: same rows in the same order (protein, [psite,] time) and pred_fc equal to the
+    reference's to within the reference's OWN integration error at its hard-wired 1e-5 / 1e-7 (measured against LSODA at 1e-12)."""
+    from phoskintime_amd.global_model import simulate as gsim
+    from phoskintime_amd.global_model import config as gcfg
+    from phoskintime_amd.global_model import NetworkEngine
+    g = np.load(f)
+    gcfg.MODEL = int(g["model"])
+    net = nm.Network.from_npz(g)
+    eng = NetworkEngine.from_npz(g)
+    prots = np.array([str(p) for p in g["proteins"]], dtype=object)
+    for j, k in enumerate(g["sm_sets"]):
+        sysm, idx = _system(g, g["X_phys"][int(k)])
+        sysm._pk_engines[gcfg.MODEL] = eng                     # the stand-in carries no topology arrays: hand it the engine of this network
+        dfp, dfr, dfph = gsim.simulate_and_measure(sysm, idx, g["tp"], g["tr"], g["tph"])
+        assert list(dfp["protein"]) == list(prots[g[f"sm{j}_p_i"]]) and np.array_equal(dfp["time"].values, g[f"sm{j}_p_t"])
+        assert list(dfr["protein"]) == list(prots[g[f"sm{j}_r_i"]]) and np.array_equal(dfr["time"].values, g[f"sm{j}_r_t"])
+        assert list(dfph["protein"]) == list(prots[g[f"sm{j}_ph_i"]]) and np.array_equal(dfph["time"].values, g[f"sm{j}_ph_t"])
+        want_sites = [idx.sites[i][s] for i, s in zip(g[f"sm{j}_ph_i"], g[f"sm{j}_ph_s"])]
+        assert list(dfph["psite"]) == want_sites
+        truth = nm.simulate_and_measure(net, nm.unpack_params(g["X_raw"][int(k)], _slices(g)), g["tp"], g["tr"], g["tph"], rtol=1e-12, atol=1e-12, mxstep=500000)
+        for df, key in ((dfp, "p_fc"), (dfr, "r_fc"), (dfph, "ph_fc")):
+            ours = df["pred_fc"].values; ref = g[f"sm{j}_{key}"]; tr_ = truth[key]
+            err_ref = np.max(np.abs(ref - tr_) / (1e-7 + 1e-5 * np.abs(tr_)))            # the reference's own error in units of its tolerance
+            err_ours = np.max(np.abs(ours - tr_) / (1e-7 + 1e-5 * np.abs(tr_)))
+            assert err_ours <= max(2.0, 1.5 * err_ref), (f.name, key, err_ours, err_ref)
+            np.testing.assert_allclose(ours, ref, rtol=1e-5 * (err_ours + err_ref + 1), atol=1e-7 * (err_ours + err_ref + 1))
+    eng.close()
+
+
+@pytest.mark.parametrize("f", NETPINS, ids=lambda f: f.stem)
+def test_population_objectives_against_reference_evaluate(f):
+    """GlobalODEBatch.evaluate(X_raw) vs the F the reference's GlobalODE_MOO._evaluate returned for the same raw vectors (verbatim call at
+    its optimiser tolerances 1e-8 / 1e-8), incl. the fail_value branch for a candidate that cannot be simulated."""
+    from phoskintime_amd.global_model import NetworkEngine
+    from phoskintime_amd.global_model.optproblem import GlobalODEBatch
+    g = np.load(f)
+    eng = NetworkEngine.from_npz(g)
+    sl = _slices(g)
+    ld = {k[3:]: g[k] for k in g.files if k.startswith("ld_")}
+    row = g["ev_defaults"]
+    defaults = {k: (row[sl[k]] if k != "tf_scale" else float(row[sl[k]][0])) for k in KEYS}
+    lam = dict(zip(("protein", "rna", "phospho", "prior"), (float(v) for v in g["ev_lambdas"])))
+    prob = GlobalODEBatch(eng, sl, ld, defaults, lam, g["times"], xl=g["xl"], xu=g["xu"], fail_value=float(g["ev_fail_value"]), loss_mode=int(g["ev_loss_mode"]))
+    assert (prob.rtol, prob.atol) == (float(g["ode_rtol"]), float(g["ode_atol"]))
+    bad = g["X_raw"][0].copy(); bad[sl["A_i"]] = np.nan
+    F = prob.evaluate(np.vstack([g["X_raw"], bad[None]]))
+    # the reference's F carries its own LSODA error at 1e-8 (relative ~1e-6 on trajectories); objectives are smooth in Y
+    np.testing.assert_allclose(F[:-1], g["ev_F"], rtol=2e-5)
+    np.testing.assert_array_equal(F[-1], g["ev_F_nan_candidate"])
+    prob.close(); eng.close()

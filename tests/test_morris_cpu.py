@@ -78,7 +78,7 @@ def test_bounds_and_problem_definitions_match_oracle():
     assert p["num_vars"] == 10 and p["names"] == ['A', 'B', 'C', 'D', 'S1', 'S2', 'S3', 'D1', 'D2', 'D3']
     assert p["bounds"][0] == [0.0, 0.1] and p["bounds"][4] == [2.0, 6.0]
     pr = define_sensitivity_problem_rand(2, list(np.ones(9)))
-    assert pr["num_vars"] == 9 and pr["names"][-3:] == ['D1', 'D2', 'D3']
+    assert pr["num_vars"] == 9 and pr["names"][-3:] == ['D1', 'D2', 'D12']
     with pytest.raises(AssertionError):
         define_sensitivity_problem_ds(3, [1.0] * 9)
 
