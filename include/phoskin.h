@@ -9,7 +9,10 @@
  *
  * Conventions
  *   model      0 = distmod (models/distmod.py), 1 = succmod (models/succmod.py), 2 = randmod (models/randmod.py)
- *   state      y = [R, P, X_1..X_m], m = n_sites (dist/succ) or 2^n_sites - 1 (rand); S = 2 + m   (<= 64)
+ *   state      y = [R, P, X_1..X_m], m = n_sites (dist/succ) or 2^n_sites - 1 (rand); S = 2 + m.  Up to 64 states a replica is a lane
+ *              group of a wavefront; beyond that (distmod / succmod n_sites 63..1276, randmod n_sites 7..20) one workgroup owns a
+ *              replica: distmod / succmod keep the default LRP12 with exact structured solves, randmod integrates with the
+ *              Rosenbrock-W method ROS34PW2 on the n-cube at 0.05 x the requested tolerances (csrc/pk_wide.hpp)
  *   theta      [A, B, C, D, S_1..S_n, D_1..D_m], P = 4 + n + m      (reference unpack_params, distmod.py:68-91,
  *              succmod.py:94-112, randmod.py:88-119); batched as a row-major [B, P] f64 matrix
  *   return     0 = ok; < 0 = argument / runtime error (see pk_last_error); never throws or aborts.
@@ -90,7 +93,8 @@ enum {
 typedef struct pk_ctx pk_ctx;
 
 int         pk_version(void);
-/* One context per GPU / per thread.  Owns a HIP stream and a small workspace; nothing else. */
+/* One context per GPU / per thread.  Owns a HIP stream, two grow-only HBM arenas (staging of the `_host` entry points; per-replica
+ * scratch of the largest random-model systems) and a page-locked host buffer for small `_host` calls -- no hipMalloc / hipFree per call. */
 pk_ctx*     pk_create(int device_id);          /* NULL on failure: reason in pk_create_error() */
 const char* pk_create_error(void);          /* thread-local; empty string after a successful pk_create */
 void        pk_destroy(pk_ctx*);
@@ -101,6 +105,9 @@ int         pk_set_stream(pk_ctx*, void* hip_stream);
 int         pk_use_own_stream(pk_ctx*);
 int         pk_synchronize(pk_ctx*);
 void        pk_default_opts(pk_solver_opts*);
+/* {staging allocations so far, staging bytes, scratch allocations, scratch bytes, page-locked allocations, page-locked bytes}: serial
+ * callers (the reference calls solve_ode once per parameter vector: paramest/normest.py:55, paramest/core.py:111,141,154) allocate once. */
+int         pk_workspace_stats(pk_ctx*, int64_t out[6]);
 
 /* Shapes (pure host arithmetic, usable without a GPU). */
 int pk_protein_n_states(int model, int n_sites);           /* S, or PK_ERR_* */

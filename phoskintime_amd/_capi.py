@@ -60,7 +60,7 @@ class SolverOpts(C.Structure):
 
 #: every symbol include/phoskin.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = (
-    "pk_version", "pk_create", "pk_create_error", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts",
+    "pk_version", "pk_create", "pk_create_error", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts", "pk_workspace_stats",
     "pk_protein_n_states", "pk_protein_n_params", "pk_protein_flat_len",
     "pk_solve_protein_batch", "pk_rhs_protein_batch", "pk_jacobian_protein_batch", "pk_steady_state_protein_batch", "pk_morris_build_batch", "pk_morris_effects_batch", "pk_score_fit_batch",
     "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
@@ -101,6 +101,7 @@ def load():
     lib.pk_use_own_stream.restype = i32; lib.pk_use_own_stream.argtypes = [vp]
     lib.pk_synchronize.restype = i32; lib.pk_synchronize.argtypes = [vp]
     lib.pk_default_opts.restype = None; lib.pk_default_opts.argtypes = [optp]
+    lib.pk_workspace_stats.restype = i32; lib.pk_workspace_stats.argtypes = [vp, C.POINTER(C.c_int64 * 6)]
     for f in ("pk_protein_n_states", "pk_protein_n_params"):
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [i32, i32]
     lib.pk_protein_flat_len.restype = i32; lib.pk_protein_flat_len.argtypes = [i32, i32, i32]
@@ -187,6 +188,12 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.pk_synchronize(self._h))
+
+    def workspace_stats(self) -> dict:
+        """Allocation counters / sizes of the context's persistent buffers (pk_workspace_stats)."""
+        out = (C.c_int64 * 6)()
+        self.check(self.lib.pk_workspace_stats(self._h, C.byref(out)))
+        return dict(zip(("stage_allocs", "stage_bytes", "scratch_allocs", "scratch_bytes", "pinned_allocs", "pinned_bytes"), (int(v) for v in out)))
 
     @property
     def handle(self):

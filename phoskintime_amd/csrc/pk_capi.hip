@@ -9,12 +9,19 @@
 #include "../../include/phoskin.h"
 #include "pk_launch.hpp"
 
+// A growable device buffer that outlives calls: the `_host` entry points stage through one, kernels that need per-replica HBM scratch
+// use another (two, so that an inner device-pointer call can never move the staging area of the `_host` call around it).
+struct pk_arena {
+  void* p = nullptr; size_t bytes = 0; long long allocs = 0;
+};
 struct pk_ctx {
   int device;
   hipStream_t own_stream;
   hipStream_t stream;
   std::string err;
   hipEvent_t ev0, ev1;
+  pk_arena stage, scratch;                       // device memory
+  void* pin = nullptr; size_t pin_bytes = 0; long long pin_allocs = 0;      // page-locked host staging for small calls
 };
 
 namespace {
@@ -29,16 +36,45 @@ int fail(pk_ctx* c, int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(ctx, PK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Make `a` hold at least `bytes` (grow-only, 1.5x + 64 KB slack so that a slowly growing batch does not reallocate every call).
+// Growing frees the old buffer, so the stream is drained first: work queued by earlier calls may still read it.
+int arena_reserve(pk_ctx* c, pk_arena& a, size_t bytes) {
+  if (bytes <= a.bytes) return PK_OK;
+  const size_t want = bytes + bytes / 2 + (64u << 10);
+  if (a.p) { PK_HIP(c, hipStreamSynchronize(c->stream)); PK_HIP(c, hipFree(a.p)); a.p = nullptr; a.bytes = 0; }
+  hipError_t e = hipMalloc(&a.p, want);
+  if (e != hipSuccess) { a.p = nullptr; return fail(c, PK_ERR_NOMEM, std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e)); }
+  a.bytes = want; ++a.allocs;
+  return PK_OK;
+}
+int pin_reserve(pk_ctx* c, size_t bytes) {
+  if (bytes <= c->pin_bytes) return PK_OK;
+  const size_t want = bytes + bytes / 2 + (64u << 10);
+  if (c->pin) { PK_HIP(c, hipStreamSynchronize(c->stream)); PK_HIP(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
+  hipError_t e = hipHostMalloc(&c->pin, want, hipHostMallocDefault);
+  if (e != hipSuccess) { c->pin = nullptr; return fail(c, PK_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+  c->pin_bytes = want; ++c->pin_allocs;
+  return PK_OK;
+}
+constexpr size_t kAlign = 256;
+size_t aligned(size_t b) { return (b + kAlign - 1) / kAlign * kAlign; }
+// calls whose host arrays total at most this many bytes travel through ONE packed page-locked buffer (one copy each way);
+// larger ones are copied array by array straight from / to the caller's (pageable) memory
+constexpr size_t kPackedLimit = 4u << 20;
+
 bool resolvent_method(int m) { return m == PK_METHOD_RODAS4 || m == PK_METHOD_LRP8 || m == PK_METHOD_LRP12; }
 int group_width(int S) { return S <= 8 ? 8 : S <= 16 ? 16 : S <= 32 ? 32 : S <= 64 ? 64 : 0; }
 
 int check_model(pk_ctx* c, int model, int n_sites) {
   if (model < 0 || model > 2) return fail(c, PK_ERR_ARG, "model must be 0 (dist), 1 (succ) or 2 (rand)");
   if (n_sites < 1) return fail(c, PK_ERR_ARG, "n_sites must be >= 1");
-  if (model == PK_MODEL_RAND && n_sites > 6) return fail(c, PK_ERR_UNSUPPORTED, "randmod: n_sites <= 6 (2^n bit-mask rows <= 64 lanes)");
-  if (model != PK_MODEL_RAND && pk::n_states(model, n_sites) > 64) return fail(c, PK_ERR_UNSUPPORTED, "S = n_sites + 2 must be <= 64 (one lane per state)");
+  if (model == PK_MODEL_RAND && n_sites > 20) return fail(c, PK_ERR_UNSUPPORTED, "randmod: n_sites <= 20 (2^n states, 2^n + n + 3 parameters per replica)");
+  if (model != PK_MODEL_RAND && pk::n_states(model, n_sites) > 64 && !pk::wide_chain_fits(pk::n_states(model, n_sites), n_sites))
+    return fail(c, PK_ERR_UNSUPPORTED, "distmod / succmod: n_sites <= 1276 (sixteen LDS vectors of n_sites + 2 doubles per workgroup)");
   return PK_OK;
 }
+// systems beyond one wavefront's lane groups (pk_wide.hpp): distmod / succmod with more than 64 states, randmod with n_sites >= 7
+bool is_wide(int model, int n_sites) { return model == PK_MODEL_RAND ? n_sites >= 7 : pk::n_states(model, n_sites) > 64; }
 
 
 int gidx(int G) { return G == 8 ? 0 : G == 16 ? 1 : G == 32 ? 2 : 3; }
@@ -105,6 +141,9 @@ void pk_destroy(pk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stage.p) (void)hipFree(c->stage.p);
+  if (c->scratch.p) (void)hipFree(c->scratch.p);
+  if (c->pin) (void)hipHostFree(c->pin);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->own_stream);
@@ -117,6 +156,13 @@ const char* pk_last_error(pk_ctx* c) { return c ? c->err.c_str() : "null context
 int pk_ctx_device(pk_ctx* c) { return c->device; }
 void* pk_ctx_stream(pk_ctx* c) { return (void*)c->stream; }
 int pk_ctx_fail(pk_ctx* c, int code, const char* msg) { return fail(c, code, msg ? msg : ""); }
+
+int pk_workspace_stats(pk_ctx* c, int64_t out[6]) {
+  if (!c || !out) return PK_ERR_ARG;
+  out[0] = c->stage.allocs; out[1] = (int64_t)c->stage.bytes; out[2] = c->scratch.allocs; out[3] = (int64_t)c->scratch.bytes;
+  out[4] = c->pin_allocs; out[5] = (int64_t)c->pin_bytes;
+  return PK_OK;
+}
 
 int pk_set_stream(pk_ctx* c, void* s) {
   if (!c) return PK_ERR_ARG;
@@ -160,6 +206,30 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   a.F = pk_protein_flat_len(model, n_sites, T); a.n_obs = n_sites; a.y0_batched = y0_is_batched ? 1 : 0; a.metric_id = metric_id;
   a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.rk4_h = o.rk4_h; a.max_steps = o.max_steps; a.clip = o.clip_nonneg; a.normalize = o.normalize; a.stage_form = o.stage_form;
 
+  if (o.kernel < PK_KERNEL_AUTO || o.kernel > PK_KERNEL_TPR) return fail(c, PK_ERR_ARG, "unknown opts->kernel");
+  if (is_wide(model, n_sites)) {
+    // one workgroup per replica (pk_wide.hpp).  distmod / succmod: LRP12 with exact structured solves; randmod: ROS34PW2-W on the n-cube
+    // (selected by any of the implicit one-step methods: there is no exact sparse resolvent for the LRP / RODAS family at this size)
+    if (B > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+    PK_HIP(c, hipSetDevice(c->device));
+    if (model == PK_MODEL_RAND) {
+      if (!resolvent_method(o.method) || o.stage_form)
+        return fail(c, PK_ERR_UNSUPPORTED, "randmod n_sites >= 7 integrates with the Rosenbrock-W kernel: method must be LRP12 / LRP8 / RODAS4 (resolvent form)");
+      double* scr = nullptr;
+      if (!pk::wide_rand_in_lds(n_sites)) {
+        rc = arena_reserve(c, c->scratch, pk::wide_rand_scratch_bytes(n_sites, B));
+        if (rc) return rc;
+        scr = (double*)c->scratch.p;
+      }
+      PK_HIP(c, pk::launch_wide_rand(a, scr, c->stream));
+    } else {
+      if (o.method != PK_METHOD_LRP12 || o.stage_form)
+        return fail(c, PK_ERR_UNSUPPORTED, "distmod / succmod with more than 64 states integrate with method LRP12 (the default) only");
+      PK_HIP(c, pk::launch_wide_chain(a, model, c->stream));
+    }
+    PK_HIP(c, hipGetLastError());
+    return PK_OK;
+  }
   const bool rand_fast = model == PK_MODEL_RAND && resolvent_method(o.method) && (o.linsolve == PK_LINSOLVE_AUTO || a.S > 64) && !o.stage_form;
   if (a.S > 64 && !rand_fast)       // n = 6: the in-register inverse of pk_rand_fast.hpp is the only solver (every `linsolve` value selects it)
     return fail(c, PK_ERR_UNSUPPORTED, "randmod n_sites = 6 (S = 65): only method RODAS4 / LRP8 in resolvent form (the generic kernels hold one state per lane)");
@@ -174,7 +244,6 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   // Thresholds from tools/gpu_bench_dev.py tprB (crossover against the lane-group kernels).  opts->kernel pins the family (sharded runs
   // that must reproduce single-GPU bits); the PK_TPR=0 / 1 environment variable (read once per process) does the same for dev A/B runs.
   static const int tpr_env_once = [] { const char* v = getenv("PK_TPR"); return v ? atoi(v) : -1; }();
-  if (o.kernel < PK_KERNEL_AUTO || o.kernel > PK_KERNEL_TPR) return fail(c, PK_ERR_ARG, "unknown opts->kernel");
   const int tpr_env = o.kernel == PK_KERNEL_GROUP ? 0 : o.kernel == PK_KERNEL_TPR ? 1 : tpr_env_once;
   const long long tpr_min = (model == PK_MODEL_SUCC) ? (n_sites <= 8 ? 16384 : 32768) : (model == PK_MODEL_RAND) ? 32768 : (n_sites <= 8 ? 32768 : 49152);
   const bool tpr = o.method == PK_METHOD_LRP12 && o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form && pk::tpr_available(model, n_sites) &&
@@ -203,7 +272,8 @@ int pk_rhs_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const dou
   if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
   PK_HIP(c, hipSetDevice(c->device));
   dim3 grid((unsigned)nblk);
-  if (S > 64) pk::launch_rand_rhs_wide(theta, y, dydt, (long long)B, n_sites, S, P, c->stream);
+  if (S > 64 && model != PK_MODEL_RAND) pk::launch_chain_rhs_wide(model, theta, y, dydt, (long long)B, n_sites, S, P, c->stream);
+  else if (S > 64) pk::launch_rand_rhs_wide(theta, y, dydt, (long long)B, n_sites, S, P, c->stream);
   else kRhs[model][gidx(G)](theta, y, dydt, (long long)B, n_sites, S, P, grid, c->stream);
   PK_HIP(c, hipGetLastError());
   return PK_OK;
@@ -221,7 +291,8 @@ int pk_jacobian_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, cons
   if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
   PK_HIP(c, hipSetDevice(c->device));
   dim3 grid((unsigned)nblk);
-  if (S > 64) pk::launch_rand_jac_wide(theta, J, (long long)B, n_sites, S, P, c->stream);
+  if (S > 64 && model != PK_MODEL_RAND) pk::launch_chain_jac_wide(model, theta, J, (long long)B, n_sites, S, P, c->stream);
+  else if (S > 64) pk::launch_rand_jac_wide(theta, J, (long long)B, n_sites, S, P, c->stream);
   else kJac[model][gidx(G)](theta, J, (long long)B, n_sites, S, P, grid, c->stream);
   PK_HIP(c, hipGetLastError());
   return PK_OK;
@@ -235,7 +306,7 @@ int pk_steady_state_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, 
   if (B == 0) return PK_OK;
   if (!theta || !y_ss) return fail(c, PK_ERR_ARG, "null pointer");
   const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites);
-  if (S > 64) return fail(c, PK_ERR_UNSUPPORTED, "steady state: S <= 64 (randmod n_sites <= 5)");
+  if (S > 64) return fail(c, PK_ERR_UNSUPPORTED, "steady state: S <= 64 (distmod / succmod n_sites <= 62, randmod n_sites <= 5)");
   const int G = group_width(S);
   const long long rpb = 256 / G, nblk = (B + rpb - 1) / rpb;
   if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
@@ -246,13 +317,48 @@ int pk_steady_state_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, 
 }
 
 // ------------------------------------------------------------------------------- host-pointer variants
+// No hipMalloc / hipFree per call: device staging comes out of the context's grow-only arena.  Small calls (the reference's own call
+// shape: ONE parameter vector per solve_ode call) additionally pack all inputs into one page-locked buffer and all outputs into
+// another region of it, so a call is H2D copy -> kernel -> D2H copy -> one stream synchronisation.
+}  // extern "C"
 namespace {
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
+struct Seg { const void* src; void* dst; size_t bytes; size_t off; };     // one host array and its offset in the staging block
+
+struct HostCall {
+  pk_ctx* c; Seg in[4]; int n_in = 0; Seg out[6]; int n_out = 0; size_t in_bytes = 0, total = 0;
+  explicit HostCall(pk_ctx* ctx) : c(ctx) {}
+  size_t add_in(const void* src, size_t bytes) { in[n_in++] = {src, nullptr, bytes, total}; const size_t o = total; total += aligned(bytes); in_bytes = total; return o; }
+  size_t add_out(void* dst, size_t bytes) { if (!dst) return (size_t)-1; out[n_out++] = {nullptr, dst, bytes, total}; const size_t o = total; total += aligned(bytes); return o; }
+  template <class T> T* dev(size_t off) const { return off == (size_t)-1 ? nullptr : reinterpret_cast<T*>((char*)c->stage.p + off); }
+  bool packed() const { return total <= kPackedLimit; }
+  int upload() {
+    int rc = arena_reserve(c, c->stage, total);
+    if (rc) return rc;
+    if (packed()) {
+      if ((rc = pin_reserve(c, total))) return rc;
+      for (int i = 0; i < n_in; ++i) std::memcpy((char*)c->pin + in[i].off, in[i].src, in[i].bytes);
+      PK_HIP(c, hipMemcpyAsync(c->stage.p, c->pin, in_bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+      for (int i = 0; i < n_in; ++i) PK_HIP(c, hipMemcpyAsync((char*)c->stage.p + in[i].off, in[i].src, in[i].bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    return PK_OK;
+  }
+  int download() {
+    if (n_out == 0) { PK_HIP(c, hipStreamSynchronize(c->stream)); return PK_OK; }
+    if (packed()) {
+      const size_t lo = out[0].off, hi = out[n_out - 1].off + out[n_out - 1].bytes;
+      PK_HIP(c, hipMemcpyAsync((char*)c->pin + lo, (char*)c->stage.p + lo, hi - lo, hipMemcpyDeviceToHost, c->stream));
+      PK_HIP(c, hipStreamSynchronize(c->stream));
+      for (int i = 0; i < n_out; ++i) std::memcpy(out[i].dst, (char*)c->pin + out[i].off, out[i].bytes);
+    } else {
+      for (int i = 0; i < n_out; ++i) PK_HIP(c, hipMemcpyAsync(out[i].dst, (char*)c->stage.p + out[i].off, out[i].bytes, hipMemcpyDeviceToHost, c->stream));
+      PK_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return PK_OK;
+  }
 };
 }  // namespace
+extern "C" {
 
 int pk_solve_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y0,
                                 int y0_is_batched, const double* t, int T, const pk_solver_opts* opts, double* sol,
@@ -265,30 +371,16 @@ int pk_solve_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, co
   if (!theta || !y0 || !t) return fail(c, PK_ERR_ARG, "theta, y0 and t must be non-null");
   const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), F = pk_protein_flat_len(model, n_sites, T);
   PK_HIP(c, hipSetDevice(c->device));
-  DevBuf d_th, d_y0, d_t, d_sol, d_flat, d_met, d_st, d_ns;
+  HostCall h(c);
   const size_t ny0 = (y0_is_batched ? (size_t)B : 1) * S;
-  PK_HIP(c, d_th.alloc((size_t)B * P * 8));
-  PK_HIP(c, d_y0.alloc(ny0 * 8));
-  PK_HIP(c, d_t.alloc((size_t)T * 8));
-  if (sol) PK_HIP(c, d_sol.alloc((size_t)B * T * S * 8));
-  if (flat) PK_HIP(c, d_flat.alloc((size_t)B * F * 8));
-  if (metric) PK_HIP(c, d_met.alloc((size_t)B * 8));
-  if (status) PK_HIP(c, d_st.alloc((size_t)B * 4));
-  if (n_steps) PK_HIP(c, d_ns.alloc((size_t)B * 8));
-  PK_HIP(c, hipMemcpyAsync(d_th.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, c->stream));
-  PK_HIP(c, hipMemcpyAsync(d_y0.p, y0, ny0 * 8, hipMemcpyHostToDevice, c->stream));
-  PK_HIP(c, hipMemcpyAsync(d_t.p, t, (size_t)T * 8, hipMemcpyHostToDevice, c->stream));
-  rc = pk_solve_protein_batch(c, model, n_sites, B, (const double*)d_th.p, (const double*)d_y0.p, y0_is_batched,
-                              (const double*)d_t.p, T, opts, (double*)d_sol.p, (double*)d_flat.p, (double*)d_met.p,
-                              metric_id, (int32_t*)d_st.p, (int32_t*)d_ns.p);
+  const size_t o_th = h.add_in(theta, (size_t)B * P * 8), o_y0 = h.add_in(y0, ny0 * 8), o_t = h.add_in(t, (size_t)T * 8);
+  const size_t o_sol = h.add_out(sol, (size_t)B * T * S * 8), o_flat = h.add_out(flat, (size_t)B * F * 8), o_met = h.add_out(metric, (size_t)B * 8),
+               o_st = h.add_out(status, (size_t)B * 4), o_ns = h.add_out(n_steps, (size_t)B * 8);
+  if ((rc = h.upload())) return rc;
+  rc = pk_solve_protein_batch(c, model, n_sites, B, h.dev<const double>(o_th), h.dev<const double>(o_y0), y0_is_batched, h.dev<const double>(o_t), T, opts,
+                              h.dev<double>(o_sol), h.dev<double>(o_flat), h.dev<double>(o_met), metric_id, h.dev<int32_t>(o_st), h.dev<int32_t>(o_ns));
   if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-  if (sol) PK_HIP(c, hipMemcpyAsync(sol, d_sol.p, (size_t)B * T * S * 8, hipMemcpyDeviceToHost, c->stream));
-  if (flat) PK_HIP(c, hipMemcpyAsync(flat, d_flat.p, (size_t)B * F * 8, hipMemcpyDeviceToHost, c->stream));
-  if (metric) PK_HIP(c, hipMemcpyAsync(metric, d_met.p, (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
-  if (status) PK_HIP(c, hipMemcpyAsync(status, d_st.p, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
-  if (n_steps) PK_HIP(c, hipMemcpyAsync(n_steps, d_ns.p, (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
-  PK_HIP(c, hipStreamSynchronize(c->stream));
-  return PK_OK;
+  return h.download();
 }
 
 int pk_rhs_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y, double* dydt) {
@@ -300,17 +392,12 @@ int pk_rhs_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, cons
   if (!theta || !y || !dydt) return fail(c, PK_ERR_ARG, "null pointer");
   const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites);
   PK_HIP(c, hipSetDevice(c->device));
-  DevBuf d_th, d_y, d_f;
-  PK_HIP(c, d_th.alloc((size_t)B * P * 8));
-  PK_HIP(c, d_y.alloc((size_t)B * S * 8));
-  PK_HIP(c, d_f.alloc((size_t)B * S * 8));
-  PK_HIP(c, hipMemcpyAsync(d_th.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, c->stream));
-  PK_HIP(c, hipMemcpyAsync(d_y.p, y, (size_t)B * S * 8, hipMemcpyHostToDevice, c->stream));
-  rc = pk_rhs_protein_batch(c, model, n_sites, B, (const double*)d_th.p, (const double*)d_y.p, (double*)d_f.p);
+  HostCall h(c);
+  const size_t o_th = h.add_in(theta, (size_t)B * P * 8), o_y = h.add_in(y, (size_t)B * S * 8), o_f = h.add_out(dydt, (size_t)B * S * 8);
+  if ((rc = h.upload())) return rc;
+  rc = pk_rhs_protein_batch(c, model, n_sites, B, h.dev<const double>(o_th), h.dev<const double>(o_y), h.dev<double>(o_f));
   if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-  PK_HIP(c, hipMemcpyAsync(dydt, d_f.p, (size_t)B * S * 8, hipMemcpyDeviceToHost, c->stream));
-  PK_HIP(c, hipStreamSynchronize(c->stream));
-  return PK_OK;
+  return h.download();
 }
 
 int pk_jacobian_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, double* J) {
@@ -322,15 +409,12 @@ int pk_jacobian_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B,
   if (!theta || !J) return fail(c, PK_ERR_ARG, "null pointer");
   const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites);
   PK_HIP(c, hipSetDevice(c->device));
-  DevBuf d_th, d_J;
-  PK_HIP(c, d_th.alloc((size_t)B * P * 8));
-  PK_HIP(c, d_J.alloc((size_t)B * S * S * 8));
-  PK_HIP(c, hipMemcpyAsync(d_th.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, c->stream));
-  rc = pk_jacobian_protein_batch(c, model, n_sites, B, (const double*)d_th.p, (double*)d_J.p);
+  HostCall h(c);
+  const size_t o_th = h.add_in(theta, (size_t)B * P * 8), o_J = h.add_out(J, (size_t)B * S * S * 8);
+  if ((rc = h.upload())) return rc;
+  rc = pk_jacobian_protein_batch(c, model, n_sites, B, h.dev<const double>(o_th), h.dev<double>(o_J));
   if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-  PK_HIP(c, hipMemcpyAsync(J, d_J.p, (size_t)B * S * S * 8, hipMemcpyDeviceToHost, c->stream));
-  PK_HIP(c, hipStreamSynchronize(c->stream));
-  return PK_OK;
+  return h.download();
 }
 
 double pk_time_solve_protein_batch(pk_ctx* c, int iters, int model, int n_sites, int64_t B, const double* theta,

@@ -1,0 +1,75 @@
+// Instantiations + launchers of the workgroup-per-replica kernels (pk_wide.hpp) for systems beyond one wavefront's lane groups.
+#include "pk_wide.hpp"
+#include "pk_launch.hpp"
+#include <atomic>
+
+namespace pk {
+
+namespace {
+constexpr size_t kLdsMax = 160 * 1024;       // gfx950: 160 KB of LDS per workgroup
+
+// raise the dynamic-LDS limit of `fn` on the current device once (per kernel and device)
+template <class K>
+hipError_t allow_lds(K fn, std::atomic<uint64_t>& ready) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0;
+  if (!bit || !(ready.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    if (e != hipSuccess) return e;
+    ready.fetch_or(bit, std::memory_order_release);
+  }
+  return hipSuccess;
+}
+}  // namespace
+
+bool wide_chain_fits(int S, int n) { return wide_chain_lds_bytes(S, n) <= kLdsMax; }
+
+hipError_t launch_wide_chain(const SolveArgs& a, int model, hipStream_t st) {
+  const size_t lds = wide_chain_lds_bytes(a.S, a.n_sites);
+  const int nt = a.S <= 64 ? 64 : a.S <= 128 ? 128 : 256;
+  hipError_t e;
+  if (model == M_DIST) {
+    static std::atomic<uint64_t> ready{0};
+    if ((e = allow_lds(wide_chain_kernel<M_DIST>, ready)) != hipSuccess) return e;
+    hipLaunchKernelGGL((wide_chain_kernel<M_DIST>), dim3((unsigned)a.B), dim3(nt), lds, st, a);
+  } else {
+    static std::atomic<uint64_t> ready{0};
+    if ((e = allow_lds(wide_chain_kernel<M_SUCC>, ready)) != hipSuccess) return e;
+    hipLaunchKernelGGL((wide_chain_kernel<M_SUCC>), dim3((unsigned)a.B), dim3(nt), lds, st, a);
+  }
+  return hipSuccess;
+}
+
+// scratch == nullptr: the vectors live in LDS (caller checked wide_rand_in_lds); else one row of `stride` doubles per replica in HBM
+bool wide_rand_in_lds(int n) { return n <= 16 && wide_rand_lds_bytes(n, true) <= kLdsMax; }
+size_t wide_rand_scratch_bytes(int n, long long B) { return wide_rand_in_lds(n) ? 0 : (size_t)B * wide_rand_scratch_doubles(n) * sizeof(double); }
+
+hipError_t launch_wide_rand(const SolveArgs& a, double* scratch, hipStream_t st) {
+  const int n = a.n_sites;
+  const int NM = 1 << n;
+  const int nt = NM <= 128 ? 64 : NM <= 256 ? 128 : 256;
+  hipError_t e;
+  if (!scratch) {
+    static std::atomic<uint64_t> ready{0};
+    if ((e = allow_lds(wide_rand_kernel<true>, ready)) != hipSuccess) return e;
+    hipLaunchKernelGGL((wide_rand_kernel<true>), dim3((unsigned)a.B), dim3(nt), wide_rand_lds_bytes(n, true), st, a, (double*)nullptr, (size_t)0);
+  } else {
+    hipLaunchKernelGGL((wide_rand_kernel<false>), dim3((unsigned)a.B), dim3(256), wide_rand_lds_bytes(n, false), st, a, scratch, wide_rand_scratch_doubles(n));
+  }
+  return hipSuccess;
+}
+
+void launch_chain_rhs_wide(int model, const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t st) {
+  const long long nblk = (B * S + 255) / 256;
+  if (model == M_DIST) hipLaunchKernelGGL((chain_rhs_wide_kernel<M_DIST>), dim3((unsigned)nblk), dim3(256), 0, st, theta, y, dydt, B, n, S, P);
+  else                 hipLaunchKernelGGL((chain_rhs_wide_kernel<M_SUCC>), dim3((unsigned)nblk), dim3(256), 0, st, theta, y, dydt, B, n, S, P);
+}
+void launch_chain_jac_wide(int model, const double* theta, double* J, long long B, int n, int S, int P, hipStream_t st) {
+  const long long nblk = (B * S + 255) / 256;
+  if (model == M_DIST) hipLaunchKernelGGL((chain_jac_wide_kernel<M_DIST>), dim3((unsigned)nblk), dim3(256), 0, st, theta, J, B, n, S, P);
+  else                 hipLaunchKernelGGL((chain_jac_wide_kernel<M_SUCC>), dim3((unsigned)nblk), dim3(256), 0, st, theta, J, B, n, S, P);
+}
+
+}  // namespace pk

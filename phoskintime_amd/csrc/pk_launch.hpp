@@ -27,6 +27,14 @@ void launch_rand_fast(const SolveArgs&, int method, hipStream_t);
 // thread-per-replica kernels for small distributive / successive systems (pk_tpr.hpp), LRP12
 bool tpr_available(int model, int n_sites);
 hipError_t launch_tpr(const SolveArgs&, int model, hipStream_t);   // sets the dynamic-LDS limit per device; its error is the caller's
+// workgroup-per-replica kernels for systems beyond 64 rows (pk_wide.hpp)
+bool wide_chain_fits(int S, int n_sites);                                   // distmod / succmod: 15 LDS vectors of S doubles
+hipError_t launch_wide_chain(const SolveArgs&, int model, hipStream_t);     // LRP12, exact solves
+bool wide_rand_in_lds(int n_sites);                                         // randmod n >= 7: 9 LDS vectors of 2^n + 1 doubles (n <= 10 / 11)
+size_t wide_rand_scratch_bytes(int n_sites, long long B);                   // 0 when the vectors fit LDS
+hipError_t launch_wide_rand(const SolveArgs&, double* scratch, hipStream_t);   // ROS34PW2-W on the n-cube
+void launch_chain_rhs_wide(int model, const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t);
+void launch_chain_jac_wide(int model, const double* theta, double* J, long long B, int n, int S, int P, hipStream_t);
 void launch_rand_rhs_wide(const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t);
 void launch_rand_jac_wide(const double* theta, double* J, long long B, int n, int S, int P, hipStream_t);
 

@@ -1,0 +1,543 @@
+// pk_wide.hpp -- per-protein systems that do not fit one wavefront's lane groups: ONE WORKGROUP PER REPLICA, state and stage
+// vectors in LDS (or, for the largest random-model systems, in an HBM scratch row), rows strided over the threads.
+//
+//   wide_chain_kernel<MODEL>   distmod with n_sites > 64 and succmod with n_sites > 62 (models/distmod.py:7-65, succmod.py:9-90): the
+//                              default integrator LRP12 (resolvent form, exact linear solves): arrow elimination with one workgroup
+//                              reduction per solve (DIST) / parallel cyclic reduction of the tridiagonal system in LDS (SUCC).
+//   wide_rand_kernel<LDSV>     randmod with n_sites >= 7 (models/randmod.py:122-247): 2^n bit-mask states on the n-cube, Jacobian
+//                              -diag(loss) + F + K with F (phosphorylation, mask -> mask | bit) strictly lower and K (dephosphorylation,
+//                              unit rate) strictly upper triangular in mask order.  No exact sparse factorisation of g I - J exists
+//                              short of a dense one, so this kernel integrates with the Rosenbrock-W method ROS34PW2 (order 3 for ANY
+//                              Jacobian approximation; tables: pk_network_solve.hpp, tools/check_ros34pw2.py) and the approximate
+//                              factorisation  g I - J ~= (D_g - F) D_g^-1 (D_g - K),  D_g = g I + diag(loss):  two sweeps over the
+//                              cube, level by level (popcount order: all masks of one level are independent).  A numpy model of exactly
+//                              this scheme takes the same number of steps as ROS34PW2 with the exact Jacobian (tools/proto_rand_wide.py).
+//                              Being order 3, it runs at 0.05 x the caller's tolerances so that the library's default options (tuned
+//                              for the order-11 LRP12) keep their margin inside the parity band.
+//
+// Outputs (sol / flat / fused Morris metric / status / n_steps) have exactly the semantics of Emitter in pk_solve_kernel.hpp.
+#pragma once
+#include "pk_solve_kernel.hpp"
+
+namespace pk {
+
+namespace rosw_tab {     // ROS34PW2 in implementation form (same numbers as namespace rosw of pk_network_solve.hpp)
+constexpr double GAM = 0.435866521508459;
+__device__ constexpr double TA[4][3] = {{0, 0, 0}, {2.0, 0, 0}, {1.41921731745576465, -0.25923221167296971378, 0},
+                                        {4.1847604823191607312, -0.2851920173554959137, 2.2942803602790417167}};
+__device__ constexpr double TC[4][3] = {{0, 0, 0}, {-4.5885607205580834861, 0, 0}, {-4.1847604823191607312, 0.2851920173554959137, 0},
+                                        {-6.3681792001283577635, -6.7956209444668361844, 2.8700986043310560892}};
+__device__ constexpr double TE[4] = {0.27774994764796811038, -1.4032398951759990242, 1.7726301276675507452, 0.5};
+}  // namespace rosw_tab
+
+// ---- workgroup reductions (every thread of the block must call; `red` holds >= 16 doubles of LDS)
+__device__ __forceinline__ double wg_max(double v, double* red) {
+  auto mx = [](double a, double b) { return (a > b || a != a) ? a : b; };      // NaN-propagating
+  for (int off = 32; off > 0; off >>= 1) v = mx(v, __shfl_xor(v, off));
+  const int nw = (blockDim.x + 63) >> 6;
+  if (nw == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int i = 1; i < nw; ++i) r = mx(r, red[i]);
+  return r;
+}
+__device__ __forceinline__ double wg_sum(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int nw = (blockDim.x + 63) >> 6;
+  if (nw == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+
+// ---- outputs of one replica owned by a whole workgroup
+struct WideOut {
+  const SolveArgs& A; long long rep; const double* y0p; double* prevv; double* red;     // prevv: LDS [2 + n_obs]
+  double s1 = 0.0, s2 = 0.0, dyn = 0.0, shift = 0.0;
+  __device__ __forceinline__ WideOut(const SolveArgs& a, long long r, const double* y0, double* pv, double* rd) : A(a), rep(r), y0p(y0), prevv(pv), red(rd) {}
+  __device__ __forceinline__ double val(double x, int row, bool nan_fill) const {
+    if (nan_fill) return __builtin_nan("");
+    double v = A.clip ? ((x < 0.0) ? 0.0 : x) : x;
+    if (A.normalize) v *= 1.0 / y0p[row];
+    return v;
+  }
+  // y: vector of S state values (LDS or global); every thread of the block calls
+  __device__ __forceinline__ void emit(int k, const double* y, bool nan_fill) {
+    const int tid = threadIdx.x, nt = blockDim.x, S = A.S, T = A.T, nobs = 2 + A.n_obs;
+    const int T5 = T > 5 ? T - 5 : 0;
+    double* solp = A.sol ? A.sol + (rep * T + k) * S : nullptr;
+    double* fl = A.flat ? A.flat + rep * A.F : nullptr;
+    if (A.metric && k == 0) {
+      double loc = 0.0;
+      for (int row = tid; row < nobs; row += nt) loc += val(y[row], row, nan_fill);
+      shift = wg_sum(loc, red) / nobs;
+    }
+    for (int row = tid; row < S; row += nt) {
+      const double v = val(y[row], row, nan_fill);
+      if (solp) solp[row] = v;
+      if (fl) {
+        if (row == 0) { if (k >= 5) fl[k - 5] = v; }
+        else if (row == 1) fl[T5 + k] = v;
+        else if (row < nobs) fl[T5 + T + (row - 2) * T + k] = v;
+      }
+      if (A.metric && row < nobs) {
+        const double pv = (k == 0) ? v : prevv[row];
+        const double xs = v - shift, d = v - pv;
+        s1 += v; s2 = __builtin_fma(xs, xs, s2); dyn = __builtin_fma(d, d, dyn);
+        prevv[row] = v;
+      }
+    }
+  }
+  __device__ __forceinline__ void finish(int status, int acc, int rej) {
+    if (A.metric) {
+      const double L = 2.0 * A.T + (double)A.T * A.n_obs;
+      const double tot = wg_sum(s1, red);
+      double m;
+      switch (A.metric_id) {
+        case PK_METRIC_TOTAL_SIGNAL: m = tot; break;
+        case PK_METRIC_MEAN_ACTIVITY: m = tot / L; break;
+        case PK_METRIC_VARIANCE: { const double q = wg_sum(s2, red); const double ms = tot / L - shift; m = q / L - ms * ms; } break;
+        case PK_METRIC_DYNAMICS: m = wg_sum(dyn, red); break;
+        default: { const double q = wg_sum(s2, red); m = sqrt(fmax(q + 2.0 * shift * tot - L * shift * shift, 0.0)); } break;
+      }
+      if (threadIdx.x == 0) A.metric[rep] = m;
+    }
+    if (threadIdx.x == 0) {
+      if (A.status) A.status[rep] = status;
+      if (A.n_steps) { A.n_steps[2 * rep] = acc; A.n_steps[2 * rep + 1] = rej; }
+    }
+  }
+};
+
+// =====================================================================================================================================
+// distributive / successive model, any n that fits LDS: LRP12 in resolvent form with exact solves.
+//   LDS doubles: 15 vectors of S + (2 + n) + 24   (=> n_sites <= 1276 in 160 KB)
+constexpr int wide_chain_vectors = 15;
+__host__ __device__ inline size_t wide_chain_lds_bytes(int S, int n) { return ((size_t)wide_chain_vectors * S + (2 + n) + 24) * sizeof(double); }
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void wide_chain_kernel(const SolveArgs A) {
+  static_assert(MODEL == M_DIST || MODEL == M_SUCC, "chain kernel: distributive / successive");
+  using Tab = ResolventTab<PK_METHOD_LRP12>;
+  extern __shared__ __align__(16) double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n = A.n_sites, S = A.S, T = A.T;
+  const long long rep = blockIdx.x;
+  if (rep >= A.B) return;
+  const double* __restrict__ th = A.theta + rep * A.P;
+  double* y = lds;            double* yn = y + S;        double* z = yn + S;       double* u6 = z + S;
+  double* c1 = u6 + S;        double* dgv = c1 + S;      double* c2 = dgv + S;                    // row coefficients (RowCoef of pk_models.hpp)
+  double* pa = c2 + S;        double* pb = pa + S;       double* pc = pb + S;      double* pr = pc + S;      // PCR buffers 0 | arrow: winv, cw in pa, pb
+  double* qa = pr + S;        double* qb = qa + S;       double* qc = qb + S;      double* qr = qc + S;      // PCR buffers 1
+  double* prevv = qr + S;     double* red = prevv + (2 + n);
+  const double* y0p = A.y0 + (A.y0_batched ? rep * S : 0);
+
+  for (int row = tid; row < S; row += nt) {
+    const RowCoef c = load_row<MODEL>(th, n, S, row);
+    c1[row] = c.c1; dgv[row] = c.dg; c2[row] = c.c2;
+    y[row] = y0p[row];
+  }
+  const double cA = th[0];
+  __syncthreads();
+  WideOut out(A, rep, y0p, prevv, red);
+  out.emit(0, y, false);
+  int status = PK_ST_OK, nacc = 0, nrej = 0;
+  if (T < 2) { out.finish(status, 0, 0); return; }
+  const double rtol = A.rtol, atol = A.atol;
+
+  // f(Y) into dst (dst != Y); all threads; ends with a barrier
+  auto rhs_into = [&](const double* Y, double* dst, const double scale) {
+    if constexpr (MODEL == M_DIST) {
+      double loc = 0.0;
+      for (int row = 2 + tid; row < S; row += nt) loc += Y[row];
+      const double sites = wg_sum(loc, red);
+      const double R = Y[0], P = Y[1];
+      for (int row = tid; row < S; row += nt) {
+        double f;
+        if (row == 0) f = __builtin_fma(dgv[0], R, cA);
+        else if (row == 1) f = __builtin_fma(c2[1], R, __builtin_fma(dgv[1], P, sites));
+        else f = __builtin_fma(c1[row], P, dgv[row] * Y[row]);
+        dst[row] = scale * f;
+      }
+    } else {
+      for (int row = tid; row < S; row += nt) {
+        double f = __builtin_fma(dgv[row], Y[row], row == 0 ? cA : 0.0);
+        if (row >= 1) f = __builtin_fma(c1[row], Y[row - 1], f);
+        if (row + 1 < S) f = __builtin_fma(c2[row], Y[row + 1], f);
+        dst[row] = scale * f;
+      }
+    }
+    __syncthreads();
+  };
+  auto err_norm = [&](const double* e, const double* ya, const double* yb) {
+    auto mx = [](double p, double r) { return (p > r || p != p) ? p : r; };
+    double m = 0.0;
+    for (int row = tid; row < S; row += nt) m = mx(m, fabs(e[row]) / __builtin_fma(rtol, fmax(fabs(ya[row]), fabs(yb[row])), atol));
+    return wg_max(m, red);
+  };
+
+  // ---- linear solves with M = I - q J
+  double qq = 0.0, sinv = 0.0, Scw = 0.0;
+  auto factor = [&](const double q) {
+    qq = q;
+    if constexpr (MODEL == M_DIST) {
+      double loc = 0.0;
+      for (int row = tid; row < S; row += nt) {
+        const double w = 1.0 / __builtin_fma(-q, dgv[row], 1.0);
+        pa[row] = w;                                               // winv
+        const double cw = (row >= 2) ? q * c1[row] * w : 0.0;      // q S_i / (1 + q d_i)
+        pb[row] = cw;
+        loc += cw;
+      }
+      Scw = wg_sum(loc, red);
+      sinv = 1.0 / __builtin_fma(-q, dgv[1] + Scw, 1.0);            // 1 + q (Dsum - sum_i cw_i): Schur pivot of the P row
+      __syncthreads();
+    }
+  };
+  // z <- M^-1 z, in place; all threads; ends with a barrier
+  auto solve = [&]() {
+    if constexpr (MODEL == M_DIST) {
+      double loc = 0.0;
+      for (int row = 2 + tid; row < S; row += nt) { const double t = z[row] * pa[row]; z[row] = t; loc += t; }
+      const double St = wg_sum(loc, red);
+      const double xR = z[0] * pa[0];
+      const double xP = __builtin_fma(qq, __builtin_fma(c2[1], xR, St), z[1]) * sinv;
+      __syncthreads();                                            // everyone has read z[0], z[1]
+      for (int row = tid; row < S; row += nt) {
+        if (row == 0) z[0] = xR;
+        else if (row == 1) z[1] = xP;
+        else z[row] = __builtin_fma(pb[row], xP, z[row]);
+      }
+      __syncthreads();
+    } else {
+      // parallel cyclic reduction on (a, b, c, r): a_i = -q c1_i, b_i = 1 - q dg_i, c_i = -q c2_i
+      double *sa = pa, *sb = pb, *sc = pc, *sr = pr, *da = qa, *db = qb, *dc = qc, *dr = qr;
+      for (int row = tid; row < S; row += nt) { sa[row] = -qq * c1[row]; sb[row] = __builtin_fma(-qq, dgv[row], 1.0); sc[row] = -qq * c2[row]; sr[row] = z[row]; }
+      __syncthreads();
+      for (int d = 1; d < S; d <<= 1) {
+        for (int row = tid; row < S; row += nt) {
+          const int lo = row - d, hi = row + d;
+          double na = 0.0, nc = 0.0, nb = sb[row], nr = sr[row];
+          if (lo >= 0) { const double al = -sa[row] / sb[lo]; na = al * sa[lo]; nb = __builtin_fma(al, sc[lo], nb); nr = __builtin_fma(al, sr[lo], nr); }
+          if (hi < S) { const double ga = -sc[row] / sb[hi]; nc = ga * sc[hi]; nb = __builtin_fma(ga, sa[hi], nb); nr = __builtin_fma(ga, sr[hi], nr); }
+          da[row] = na; db[row] = nb; dc[row] = nc; dr[row] = nr;
+        }
+        __syncthreads();
+        double* t;
+        t = sa; sa = da; da = t; t = sb; sb = db; db = t; t = sc; sc = dc; dc = t; t = sr; sr = dr; dr = t;
+      }
+      for (int row = tid; row < S; row += nt) z[row] = sr[row] / sb[row];
+      __syncthreads();
+    }
+  };
+
+  double tc = A.t[0];
+  int k = 1;
+  double te = A.t[1];
+  double h;
+  {
+    rhs_into(y, z, 1.0);
+    const double d0 = err_norm(y, y, y), d1 = err_norm(z, y, y);
+    h = (d0 > 1e-5 && d1 > 1e-5) ? 0.01 * d0 / d1 : 1e-6;
+    if (A.h0 > 0.0) h = A.h0;
+    if (!(h > 0.0) || h != h) h = 1e-6;
+  }
+  auto fail_from = [&](int kk) { for (; kk < T; ++kk) out.emit(kk, y, true); };
+  bool after_reject = false;
+  while (true) {
+    if (nacc + nrej >= A.max_steps) { status |= PK_ST_MAXSTEPS; fail_from(k); break; }
+    const bool last = (tc + 1.0001 * h >= te);
+    const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
+    if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; fail_from(k); break; }
+    factor(Tab::GAM * hs);
+    rhs_into(y, z, hs);
+    solve();
+    for (int row = tid; row < S; row += nt) { yn[row] = __builtin_fma(Tab::B[0], z[row], y[row]); u6[row] = 0.0; }
+    __syncthreads();
+    for (int kk = 1; kk < Tab::NS; ++kk) {
+      solve();
+      const double bk = Tab::B[kk], ek = Tab::E[kk];
+      for (int row = tid; row < S; row += nt) { yn[row] = __builtin_fma(bk, z[row], yn[row]); u6[row] = __builtin_fma(ek, z[row], u6[row]); }
+      __syncthreads();
+    }
+    const double err = err_norm(u6, y, yn);
+    if (err != err || err > 1e300) {
+      ++nrej; after_reject = true; h = 0.1 * hs;
+      double bad = 0.0;
+      for (int row = tid; row < S; row += nt) if (nonfinite(y[row]) || nonfinite(c1[row]) || nonfinite(dgv[row])) bad = 1.0;
+      if (nonfinite(cA)) bad = 1.0;
+      if (wg_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
+      continue;
+    }
+    double fac = root_q(err, Tab::Q) * (1.0 / 0.9);
+    fac = fmax(1.0 / 6.0, fmin(5.0, fac));
+    double hnew = hs / fac;
+    if (err <= 1.0) {
+      ++nacc;
+      for (int row = tid; row < S; row += nt) y[row] = yn[row];
+      __syncthreads();
+      tc += hs;
+      if (after_reject) hnew = fmin(hnew, hs);
+      after_reject = false;
+      if (last) {
+        tc = te;
+        out.emit(k, y, false);
+        ++k;
+        h = (hs < h) ? fmax(hnew, h) : hnew;
+        if (k >= T) break;
+        te = A.t[k];
+      } else {
+        h = hnew;
+      }
+    } else {
+      ++nrej; after_reject = true;
+      h = hnew;
+    }
+  }
+  out.finish(status, nacc, nrej);
+}
+
+// =====================================================================================================================================
+// random model on the n-cube.  Vectors of S = 2^n + 1 doubles: y, Ys, U0..U3, f, loss (index 1 + mask), dinv : 9 vectors
+constexpr int wide_rand_vectors = 9;
+__host__ __device__ inline size_t wide_rand_small_doubles(int n) { return (size_t)n + (2 + n) + 24; }                 // Sr, prevv, red
+__host__ __device__ inline size_t wide_rand_lds_bytes(int n, bool ldsv) {                                              // + lvl, binomials [, ord]
+  const size_t NM = (size_t)1 << n, S = NM + 1;
+  return ((ldsv ? (size_t)wide_rand_vectors * S : 0) + wide_rand_small_doubles(n)) * sizeof(double) + ((n + 2) + 21 * 21 + (ldsv ? NM : 0)) * sizeof(int);
+}
+// doubles of HBM scratch per replica when the vectors do not fit LDS (9 vectors + the level-order table)
+__host__ __device__ inline size_t wide_rand_scratch_doubles(int n) { const size_t NM = (size_t)1 << n, S = NM + 1; return wide_rand_vectors * S + (NM + 1) / 2 + 1; }
+
+template <bool LDSV>
+__global__ __launch_bounds__(256) void wide_rand_kernel(const SolveArgs A, double* __restrict__ scratch, const size_t stride) {
+  using namespace rosw_tab;
+  extern __shared__ __align__(16) double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n = A.n_sites, NM = 1 << n, S = A.S, T = A.T;
+  const long long rep = blockIdx.x;
+  if (rep >= A.B) return;
+  const double* __restrict__ th = A.theta + rep * A.P;
+  double* small = LDSV ? lds + (size_t)wide_rand_vectors * S : lds;
+  double* vec = LDSV ? lds : scratch + (size_t)rep * stride;
+  double* y = vec;            double* Ys = y + S;
+  double* U[4] = {Ys + S, Ys + 2 * (size_t)S, Ys + 3 * (size_t)S, Ys + 4 * (size_t)S};
+  double* f = Ys + 5 * (size_t)S;     double* loss = f + S;       double* dinv = loss + S;
+  double* Sr = small;         double* prevv = Sr + n;     double* red = prevv + (2 + n);
+  int* lvl = reinterpret_cast<int*>(red + 24);       int* binom = lvl + (n + 2);
+  int* ord = LDSV ? binom + 21 * 21 : reinterpret_cast<int*>(vec + (size_t)wide_rand_vectors * S);      // masks in popcount-level order
+  const double* y0p = A.y0 + (A.y0_batched ? rep * S : 0);
+  const double cA = th[0], cB = th[1], cC = th[2], cD = th[3];
+
+  // ---- tables: binomials, popcount levels, masks in level order
+  if (tid == 0) {
+    for (int a = 0; a <= 20; ++a) for (int b = 0; b <= 20; ++b) binom[a * 21 + b] = (b == 0) ? 1 : (a == 0 ? 0 : binom[(a - 1) * 21 + b - 1] + binom[(a - 1) * 21 + b]);
+    lvl[0] = 0;
+    for (int L = 0; L <= n; ++L) lvl[L + 1] = lvl[L] + binom[n * 21 + L];
+  }
+  for (int j = tid; j < n; j += nt) Sr[j] = th[4 + j];
+  __syncthreads();
+  double sumS = 0.0;
+  for (int j = 0; j < n; ++j) sumS += Sr[j];                           // same order as the reference (randmod.py:145-151)
+  for (int m = tid; m < NM; m += nt) {
+    int kk = __popc(m), rank = 0;
+    { int c = kk; for (int j = n - 1; j >= 0 && c > 0; --j) if ((m >> j) & 1) { rank += binom[j * 21 + c]; --c; } }
+    ord[lvl[kk] + rank] = m;
+    double l;
+    if (m == 0) l = cD + sumS;
+    else {
+      const int lsb = __builtin_ctz(m);
+      double o = 0.0;
+      for (int j = 0; j < n; ++j) o += ((m >> j) & 1) ? 1.0 : Sr[j < lsb ? j : lsb];     // same accumulation order as load_row<M_RAND>
+      l = o + th[4 + n + m - 1];
+    }
+    loss[1 + m] = l;
+  }
+  if (tid == 0) loss[0] = cB;
+  for (int row = tid; row < S; row += nt) y[row] = y0p[row];
+  __syncthreads();
+  WideOut out(A, rep, y0p, prevv, red);
+  out.emit(0, y, false);
+  int status = PK_ST_OK, nacc = 0, nrej = 0;
+  if (T < 2) { out.finish(status, 0, 0); return; }
+  const double rtol = 0.05 * A.rtol, atol = 0.05 * A.atol;            // order-3 method: see the header of this file
+
+  // dst = f(Y) + sum_u coef[u] * U[u]   (dst != Y); ends with a barrier
+  auto rhs_into = [&](const double* Y, double* dst, const int nu, const double* coef) {
+    for (int row = tid; row < S; row += nt) {
+      double v;
+      if (row == 0) v = __builtin_fma(-cB, Y[0], cA);
+      else {
+        const int m = row - 1;
+        double lo = 0.0, hi = 0.0;
+        for (int mm = m; mm; mm &= mm - 1) lo += Y[1 + (m ^ (mm & -mm))];
+        for (int mm = ~m & (NM - 1); mm; mm &= mm - 1) hi += Y[1 + (m | (mm & -mm))];
+        v = __builtin_fma(-loss[row], Y[row], hi);
+        v = (m == 0) ? __builtin_fma(cC, Y[0], v) : __builtin_fma(Sr[__builtin_ctz(m)], lo, v);
+      }
+      for (int u = 0; u < nu; ++u) v = __builtin_fma(coef[u], U[u][row], v);
+      dst[row] = v;
+    }
+    __syncthreads();
+  };
+  // x = W~^-1 r   (x != r): forward sweep over ascending levels, backward over descending; ends with a barrier
+  auto solve = [&](const double* r, double* x) {
+    if (tid == 0) {
+      const double xR = r[0] * dinv[0];
+      x[0] = xR;
+      x[1] = __builtin_fma(cC, xR, r[1]) * dinv[1];
+    }
+    __syncthreads();
+    for (int L = 1; L <= n; ++L) {
+      for (int idx = lvl[L] + tid; idx < lvl[L + 1]; idx += nt) {
+        const int m = ord[idx];
+        double lo = 0.0;
+        for (int mm = m; mm; mm &= mm - 1) lo += x[1 + (m ^ (mm & -mm))];
+        x[1 + m] = __builtin_fma(Sr[__builtin_ctz(m)], lo, r[1 + m]) * dinv[1 + m];
+      }
+      __syncthreads();
+    }
+    for (int L = n - 1; L >= 0; --L) {
+      for (int idx = lvl[L] + tid; idx < lvl[L + 1]; idx += nt) {
+        const int m = ord[idx];
+        double hi = 0.0;
+        for (int mm = ~m & (NM - 1); mm; mm &= mm - 1) hi += x[1 + (m | (mm & -mm))];
+        x[1 + m] = __builtin_fma(hi, dinv[1 + m], x[1 + m]);
+      }
+      __syncthreads();
+    }
+  };
+  auto norm_of = [&](const double* e, const double* ya, const double* yb) {
+    auto mx = [](double p, double r) { return (p > r || p != p) ? p : r; };
+    double m = 0.0;
+    for (int row = tid; row < S; row += nt) m = mx(m, fabs(e[row]) / __builtin_fma(rtol, fmax(fabs(ya[row]), fabs(yb[row])), atol));
+    return wg_max(m, red);
+  };
+
+  double tc = A.t[0];
+  int k = 1;
+  double te = A.t[1];
+  double h;
+  {
+    rhs_into(y, f, 0, nullptr);
+    const double d0 = norm_of(y, y, y), d1 = norm_of(f, y, y);
+    h = (d0 > 1e-5 && d1 > 1e-5) ? 0.01 * d0 / d1 : 1e-6;
+    if (A.h0 > 0.0) h = A.h0;
+    if (!(h > 0.0) || h != h) h = 1e-6;
+  }
+  auto fail_from = [&](int kk) { for (; kk < T; ++kk) out.emit(kk, y, true); };
+  bool after_reject = false;
+  while (true) {
+    if (nacc + nrej >= A.max_steps) { status |= PK_ST_MAXSTEPS; fail_from(k); break; }
+    const bool last = (tc + 1.0001 * h >= te);
+    const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
+    if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; fail_from(k); break; }
+    const double hinv = 1.0 / hs, g = hinv * (1.0 / GAM);
+    for (int row = tid; row < S; row += nt) dinv[row] = 1.0 / (g + loss[row]);
+    __syncthreads();
+    for (int sg = 0; sg < 4; ++sg) {
+      const double* Y = y;
+      if (sg > 0) {
+        for (int row = tid; row < S; row += nt) {
+          double v = y[row];
+          for (int u = 0; u < sg; ++u) v = __builtin_fma(TA[sg][u], U[u][row], v);
+          Ys[row] = v;
+        }
+        __syncthreads();
+        Y = Ys;
+      }
+      double coef[3];
+      for (int u = 0; u < 3; ++u) coef[u] = TC[sg][u] * hinv;
+      rhs_into(Y, f, sg, coef);
+      solve(f, U[sg]);
+    }
+    // new value = stage-4 point + U4 (stiffly accurate); error estimate = sum E_i U_i (kept in f)
+    for (int row = tid; row < S; row += nt) {
+      Ys[row] += U[3][row];
+      f[row] = TE[0] * U[0][row] + TE[1] * U[1][row] + TE[2] * U[2][row] + TE[3] * U[3][row];
+    }
+    __syncthreads();
+    const double err = norm_of(f, y, Ys);
+    if (err != err || err > 1e300) {
+      ++nrej; after_reject = true; h = 0.1 * hs;
+      double bad = 0.0;
+      for (int row = tid; row < S; row += nt) if (nonfinite(y[row]) || nonfinite(loss[row])) bad = 1.0;
+      if (nonfinite(cA) || nonfinite(cC)) bad = 1.0;
+      if (wg_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
+      continue;
+    }
+    double fac = cbrt(err) * (1.0 / 0.9);
+    fac = fmax(1.0 / 6.0, fmin(5.0, fac));
+    double hnew = hs / fac;
+    if (err <= 1.0) {
+      ++nacc;
+      for (int row = tid; row < S; row += nt) y[row] = Ys[row];
+      __syncthreads();
+      tc += hs;
+      if (after_reject) hnew = fmin(hnew, hs);
+      after_reject = false;
+      if (last) {
+        tc = te;
+        out.emit(k, y, false);
+        ++k;
+        h = (hs < h) ? fmax(hnew, h) : hnew;
+        if (k >= T) break;
+        te = A.t[k];
+      } else {
+        h = hnew;
+      }
+    } else {
+      ++nrej; after_reject = true;
+      h = hnew;
+    }
+  }
+  out.finish(status, nacc, nrej);
+}
+
+// =====================================================================================================================================
+// Right-hand side / Jacobian / steady state for the wide systems of the distributive and successive models: one thread per (replica, row).
+template <int MODEL>
+__global__ void chain_rhs_wide_kernel(const double* __restrict__ theta, const double* __restrict__ y, double* __restrict__ dydt,
+                                      const long long B, const int n, const int S, const int P) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * S) return;
+  const long long rep = gid / S;
+  const int row = (int)(gid - rep * S);
+  const RowCoef c = load_row<MODEL>(theta + rep * P, n, S, row);
+  const double* yr = y + rep * S;
+  double f = __builtin_fma(c.dg, yr[row], c.bias);
+  if constexpr (MODEL == M_DIST) {
+    if (row == 1) { double s = 0.0; for (int i = 2; i < S; ++i) s += yr[i]; f = __builtin_fma(c.c2, yr[0], f) + s; }
+    else if (row >= 2) f = __builtin_fma(c.c1, yr[1], f);
+  } else {
+    if (row >= 1) f = __builtin_fma(c.c1, yr[row - 1], f);
+    if (row + 1 < S) f = __builtin_fma(c.c2, yr[row + 1], f);
+  }
+  dydt[gid] = f;
+}
+
+template <int MODEL>
+__global__ void chain_jac_wide_kernel(const double* __restrict__ theta, double* __restrict__ J, const long long B, const int n,
+                                      const int S, const int P) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * S) return;
+  const long long rep = gid / S;
+  const int row = (int)(gid - rep * S);
+  const RowCoef c = load_row<MODEL>(theta + rep * P, n, S, row);
+  double* Jr = J + gid * S;
+  for (int j = 0; j < S; ++j) Jr[j] = 0.0;
+  if constexpr (MODEL == M_DIST) {
+    if (row == 1) { for (int j = 2; j < S; ++j) Jr[j] = 1.0; Jr[0] = c.c2; }
+    else if (row >= 2) Jr[1] = c.c1;
+  } else {
+    if (row >= 1) Jr[row - 1] = c.c1;
+    if (row + 1 < S) Jr[row + 1] = c.c2;
+  }
+  Jr[row] = c.dg;
+}
+
+}  // namespace pk

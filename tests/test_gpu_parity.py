@@ -142,7 +142,9 @@ def test_argument_errors(eng):
     with pytest.raises(ValueError):
         eng.solve_ode_batch(0, np.ones((2, 12)), np.ones(5), 4, pm.TIME_POINTS)          # wrong S
     with pytest.raises(PhoskinError):
-        eng.solve_ode_batch(2, np.ones((1, 4 + 7 + 127)), np.ones(129), 7, pm.TIME_POINTS)  # randmod n = 7: 128 bit-mask rows > 64 lanes
+        eng.solve_ode_batch(2, np.ones((1, 4 + 7 + 127)), np.ones(129), 7, pm.TIME_POINTS, method="rk4")  # randmod n = 7 runs (pk_wide.hpp), but not explicitly
+    with pytest.raises(ValueError):
+        eng.n_states(2, 21)                                                                # 2^21 states: beyond the ABI's range
     with pytest.raises(PhoskinError):
         eng.solve_ode_batch(2, np.ones((1, 4 + 6 + 63)), np.ones(65), 6, pm.TIME_POINTS, method="bdf2")  # n = 6 only has the resolvent kernels
     with pytest.raises(PhoskinError):
@@ -287,6 +289,38 @@ def test_host_pointer_entry_points_agree_with_device_ones(eng, golden_files):
     assert rc == 0 and not st.any()
     dev = _np(eng.solve_ode_batch(model, th, y0, n, t).sol)
     np.testing.assert_array_equal(sol, dev)
+
+
+def test_serial_host_calls_allocate_once(eng):
+    """the reference calls solve_ode once per parameter vector (paramest/normest.py:55, paramest/core.py:111,141,154);
+    round 1 paid up to 8 hipMalloc + 8 hipFree per such call.  Now the context owns grow-only arenas: 1 000 serial one-theta calls
+    through the host entry point allocate device and page-locked memory exactly once, and a larger batch grows the arena once more."""
+    from phoskintime_amd import batch, models
+    ctx = batch.get_context()
+    models.set_model("distmod")
+    rng = np.random.default_rng(0)
+    th = rng.uniform(0.1, 3.0, 12)
+    sol0, flat0 = models.solve_ode(th, np.ones(6), 4, pm.TIME_POINTS)          # first call may allocate
+    before = ctx.workspace_stats()
+    for _ in range(1000):
+        sol, flat = models.solve_ode(th, np.ones(6), 4, pm.TIME_POINTS)
+    after = ctx.workspace_stats()
+    assert after == before, (before, after)
+    np.testing.assert_array_equal(sol, sol0); np.testing.assert_array_equal(flat, flat0)
+    assert pm.band_error(sol, np.clip(pm.solve_exact_lti(pm.DIST, th, np.ones(6), 4, pm.TIME_POINTS), 0, None)) <= 0.1
+    assert before["stage_bytes"] > 0 and before["pinned_bytes"] > 0
+    # a batch beyond the packed limit (4 MB) takes the array-by-array path out of the same (grown) arena; results identical
+    thB = np.tile(th, (20000, 1))
+    lib, h = ctx.lib, ctx.handle
+    solB = np.empty((20000, 14, 6)); st = np.empty(20000, np.int32)
+    ctx.check(lib.pk_solve_protein_batch_host(h, 0, 4, 20000, thB.ctypes.data, np.ones(6).ctypes.data, 0, pm.TIME_POINTS.ctypes.data, 14, None,
+                                              solB.ctypes.data, None, None, 0, st.ctypes.data, None))
+    grown = ctx.workspace_stats()
+    assert grown["stage_allocs"] == before["stage_allocs"] + 1 and grown["pinned_allocs"] == before["pinned_allocs"]
+    assert not st.any()
+    np.testing.assert_array_equal(solB[0], solB[-1])
+    assert np.abs(solB[0] - sol).max() <= 1e-9                    # B = 1 runs the lane-group kernel, B = 20 000 may run another family
+    models.set_model("randmod")
 
 
 def test_resolvent_form_equals_classical_stage_form(eng, golden_files):

@@ -38,7 +38,7 @@ def test_softplus_unpack_matches_reference_unpack_params(f):
     g = np.load(f)
     eng = NetworkEngine.from_npz(g)
     assert eng.n_var == g["X_raw"].shape[1]
-    np.testing.assert_allclose(eng.unpack_batch(g["X_raw"]).cpu().numpy(), g["X_phys"], rtol=2e-16, atol=0)
+    np.testing.assert_allclose(eng.unpack_batch(g["X_raw"]).cpu().numpy(), g["X_phys"], rtol=5e-16, atol=0)      # device exp / log1p vs libm: within 2 ulp
     eng.close()
 
 

@@ -135,3 +135,20 @@ def test_steady_state_restatement_matches_reference_slsqp():
         y = pm.initial_condition(kind, int(n))
         assert y.shape == g[key].shape
         np.testing.assert_allclose(y, g[key], rtol=2e-6, atol=1e-9, err_msg=key)
+
+
+def test_wide_fixtures_pin_the_oracle_too(golden_wide_files):
+    """Systems beyond 64 states (distmod / succmod n = 64, 100; randmod n = 7, 8): the oracle's RHS against the reference's, bit for bit,
+    the analytic Jacobian against the reference's RHS-probed columns, and one verbatim default-tolerance trajectory per model."""
+    seen = set()
+    for f in golden_wide_files:
+        g, model, n = _load(f)
+        for k in range(2):
+            np.testing.assert_array_equal(pm.rhs(model, g["y_rand"][k], 0.0, g["theta"][k], n), g["rhs_y_rand"][k])
+        J = pm.jacobian_analytic(model, g["theta"][0], n)
+        assert np.abs(J - g["jac"][0]).max() <= 4e-15 * max(1.0, np.abs(g["jac"][0]).max())
+        if model not in seen and pm.n_states(model, n) <= 130:          # LSODA on a pure-Python RHS: one case per model
+            seen.add(model)
+            sol, flat = pm.solve_ode(model, g["theta"][0], g["y0"][0], n, g["t"])
+            np.testing.assert_array_equal(sol, g["sol_default"][0])
+            np.testing.assert_array_equal(flat, g["flat_default"][0])
