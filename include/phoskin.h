@@ -209,7 +209,7 @@ int pk_network_jacobian_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int 
  * (t[0] = initial time), Y [B,T,S] device.  Integrator: ROS34PW2 Rosenbrock-W with the per-protein diagonal blocks of the analytic
  * Jacobian for every opts->method except PK_METHOD_DP5, which selects the reference's explicit RK45 (jacspeedup.solve_custom,
  * jacspeedup.py:31-64; h0 = dt_init, 0 -> 0.05; max_steps <= 0 -> 2 000 000).  opts->rtol / atol / h0 / max_steps are honoured.
- * Topologies 0, 1, 4; the combinatorial one (2) with <= 3 sites per protein under the W-method and with any block size under DP5. */
+ * All four topologies; combinatorial blocks (2) up to 3 sites per protein run out of registers, larger ones (<= 16 sites) in the LDS kernel. */
 int pk_network_simulate_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
                               const double* t_host, int T, const pk_solver_opts* opts, double* Y, int32_t* status, int32_t* n_steps);
 /* global_model.params.unpack_params (softplus of the raw decision vectors): x_raw [B,n_var] -> x_phys [B,n_var]. */

@@ -164,6 +164,7 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
   if (n->solve_lds_bytes > 48 * 1024 && n->solve_lds_bytes <= 160 * 1024) {
     (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
     (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
+    (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
     (void)hipFuncSetAttribute((const void*)pk::net_solve_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n->solve_lds_bytes);
   }
   return n;
@@ -220,9 +221,11 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   if (!x || !y0 || !Y) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
   if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
   const bool dp5 = opts_in && opts_in->method == PK_METHOD_DP5;
-  if (!dp5 && n->d.model == 2 && (n->max_sites > 3 || n->d.N > 256))
-    return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate, combinatorial topology: <= 3 sites per protein (8 phospho states per thread) and N <= 256");
-  if (!dp5 && n->d.model != 2 && n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
+  if (n->d.model == 2 && n->max_sites > 16) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "combinatorial topology: <= 16 sites per protein");
+  // combinatorial blocks: <= 3 sites per protein (and N <= 256) run one thread per protein out of registers (pk_network_solve_reg2.hpp);
+  // larger blocks run in the general LDS kernel with the same approximate factorisation, swept serially by the protein's thread
+  const bool comb_reg = n->d.model == 2 && n->max_sites <= 3 && n->d.N <= 256;
+  if (!dp5 && !(n->d.model == 2 && comb_reg) && n->solve_lds_bytes > 160 * 1024) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "network too large for one workgroup's LDS (160 KiB)");
   if (n->d.S > 1024 || n->d.N > 512) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "simulate: S <= 1024 states and N <= 512 proteins per network");
   for (int k = 1; k < T; ++k) if (!(t_host[k] > t_host[k - 1])) return pk_ctx_fail(c, PK_ERR_ARG, "t must be strictly increasing");
   pk_solver_opts o;
@@ -286,14 +289,14 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   }
   // Register-resident kernel (one thread per protein) when every block fits its per-thread arrays; opts->linsolve ==
   // PK_LINSOLVE_STRUCTURED forces the LDS kernel (kept as the general fallback and as the A/B reference).
-  if (n->d.model == 2) {
+  if (comb_reg && o.linsolve != PK_LINSOLVE_STRUCTURED) {
     const int threads2 = ((n->d.N + 63) / 64) * 64;
     if (n->max_sites <= 2) hipLaunchKernelGGL((pk::net_solve_reg2_kernel<2>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
     else                   hipLaunchKernelGGL((pk::net_solve_reg2_kernel<3>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
     hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e2));
   }
-  const bool reg_ok = n->d.N <= 256 && n->max_sites <= 8 && n->solve_reg_lds_bytes <= 64 * 1024 && o.linsolve != PK_LINSOLVE_STRUCTURED;
+  const bool reg_ok = n->d.model != 2 && n->d.N <= 256 && n->max_sites <= 8 && n->solve_reg_lds_bytes <= 64 * 1024 && o.linsolve != PK_LINSOLVE_STRUCTURED;
   if (reg_ok) {
     const int threads = ((n->d.N + 63) / 64) * 64;
     const size_t lb = n->solve_reg_lds_bytes;
@@ -312,6 +315,7 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
     if (const char* e = getenv("PK_NET_THREADS")) { const int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && n->d.S <= 4 * v && n->d.N <= 2 * v) threads = v; }
     if (n->d.model == 0)      hipLaunchKernelGGL(pk::net_solve_kernel<0>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
     else if (n->d.model == 1) hipLaunchKernelGGL(pk::net_solve_kernel<1>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
+    else if (n->d.model == 2) hipLaunchKernelGGL(pk::net_solve_kernel<2>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
     else                      hipLaunchKernelGGL(pk::net_solve_kernel<4>, dim3((unsigned)B), dim3(threads), n->solve_lds_bytes, stream, n->d, a);
   }
   hipError_t e = hipGetLastError();

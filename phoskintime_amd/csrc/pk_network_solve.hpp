@@ -124,7 +124,18 @@ __global__ __launch_bounds__(256, 3) void net_solve_kernel(const NetDev n, const
       const double* Dp = L.p + sl.Dp + ss;
       const double* Sr = L.Sall + ss;
       winv[st] = 1.0 / (g + Bi);
-      if (model == 1) {
+      if (model == 2) {
+        // combinatorial block of any size (2^ns bit-pattern states): -diag(loss) + F (phosphorylation, strictly lower in mask order) +
+        // K (dephosphorylation, strictly upper).  W-method licence once more: g I - J_block ~= (D_g - F) D_g^-1 (D_g - K), so only the
+        // pivots 1 / (g + loss_m) are stored; the two sweeps run in block_solve (same scheme as pk_network_solve_reg2.hpp, any ns)
+        cR[i] = Ci; gP[i] = 1.0;
+        const int nst = 1 << ns;
+        for (int m = 0; m < nst; ++m) {
+          double loss = (m == 0) ? Di : 0.0;
+          for (int j = 0; j < ns; ++j) loss += ((m >> j) & 1) ? (Ei + Dp[j] + Di) : Sr[j];
+          winv[st + 1 + m] = 1.0 / (g + loss);
+        }
+      } else if (model == 1) {
         // tridiagonal over P0, P1..Pns: Thomas pivots
         cR[i] = Ci; gP[i] = 1.0;
         double d = g + Di + (ns ? Sr[0] : 0.0);
@@ -163,7 +174,19 @@ __global__ __launch_bounds__(256, 3) void net_solve_kernel(const NetDev n, const
       const double* Sr = L.Sall + ss;
       const double xR = r[st] * winv[st];
       x[st] = xR;
-      if (model == 1) {
+      if (model == 2) {
+        const int nst = 1 << ns;
+        for (int m = 0; m < nst; ++m) {                              // (D_g - F) u = r : ascending masks
+          double a = r[st + 1 + m] + ((m == 0) ? cR[i] * xR : 0.0);
+          for (int mm = m; mm; mm &= mm - 1) { const int bit = mm & -mm; a = __builtin_fma(Sr[__builtin_ctz(bit)], x[st + 1 + (m ^ bit)], a); }
+          x[st + 1 + m] = a * winv[st + 1 + m];
+        }
+        for (int m = nst - 2; m >= 0; --m) {                         // (D_g - K) x = D_g u : descending masks
+          double hi = 0.0;
+          for (int mm = ~m & (nst - 1); mm; mm &= mm - 1) hi += x[st + 1 + (m | (mm & -mm))];
+          x[st + 1 + m] = __builtin_fma(Ei * hi, winv[st + 1 + m], x[st + 1 + m]);
+        }
+      } else if (model == 1) {
         // Thomas: forward sweep (lower entries -k_{q-1}), back substitution (upper entries -E); x doubles as work space
         double prev = r[st + 1] + cR[i] * xR;
         x[st + 1] = prev;
@@ -189,8 +212,8 @@ __global__ __launch_bounds__(256, 3) void net_solve_kernel(const NetDev n, const
       const int i = tid + q * nt;
       if (i >= N) break;
       double tot;
-      if (p_drv[q] >= 0) tot = L.Kt[p_drv[q]];
-      else { tot = 0.0; for (int m_ = 0; m_ <= p_ns[q]; ++m_) tot += L.y[p_st[q] + 1 + m_]; }
+      if (model != 2 && p_drv[q] >= 0) tot = L.Kt[p_drv[q]];        // the combinatorial RHS ignores driver_map (jacspeedup.py:319-327)
+      else { tot = 0.0; const int cnt = (model == 2) ? (1 << p_ns[q]) : 1 + p_ns[q]; for (int m_ = 0; m_ < cnt; ++m_) tot += L.y[p_st[q] + 1 + m_]; }
       L.Pvec[i] = tot;
     }
     __syncthreads();

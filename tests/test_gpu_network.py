@@ -145,20 +145,19 @@ def test_network_simulate_edge_cases():
     with pytest.raises(PhoskinError):
         eng.simulate_batch(X, [0.0, 1.0, 1.0])
     eng.close()
-    # combinatorial topology: supported up to 3 sites per protein; a 4-site protein is refused, not mis-integrated
+    # combinatorial topology: beyond 16 sites per protein (65 536-state blocks) the request is refused, not mis-integrated
     from phoskintime_amd.global_model import synthetic
     net4 = synthetic.make_network(N=8, total_sites=12, n_K=4, n_tf_edges=10, model=0, seed=5)
     net4["model"] = 2
-    ns = net4["n_sites"].copy(); ns[:] = 1; ns[0] = 4
+    ns = net4["n_sites"].copy(); ns[:] = 1; ns[0] = 17
     net4["n_sites"] = ns
     net4["offset_s"] = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int32)
     net4["offset_y"] = np.concatenate([[0], np.cumsum(1 + (1 << ns.astype(np.int64)))[:-1]]).astype(np.int32)
     tot = int(ns.sum())
     net4["W_indptr"] = np.arange(tot + 1, dtype=np.int32); net4["W_indices"] = np.zeros(tot, np.int32); net4["W_data"] = np.ones(tot)
-    e2 = NetworkEngine(**net4)
     with pytest.raises(PhoskinError):
+        e2 = NetworkEngine(**net4)
         e2.simulate_batch(np.ones((1, e2.n_var)), [0.0, 1.0])
-    e2.close()
 
 
 @pytest.mark.parametrize("m", [0, 2])
@@ -433,11 +432,12 @@ def test_population_evaluation_matches_elementwise_restatement():
     prob.close(); eng.close()
 
 
-def test_combinatorial_blocks_beyond_three_sites_through_the_explicit_integrator():
-    """The combinatorial topology with up to 5 sites per protein (33-state blocks): the W-method kernels stop at 3 sites, the explicit
-    RK45 only needs right-hand sides.  Checked against the oracle's restatement of the reference's RK45 loop, same step counts."""
+def test_combinatorial_blocks_beyond_three_sites():
+    """The combinatorial topology with up to 5 sites per protein (33-state blocks; global_model/models.py:323-485 has no block-size limit).
+    Round 1 had only the explicit RK45 twin for them; now the production W-method integrates them too (general LDS kernel, the block's
+    two triangular sweeps done serially by the protein's thread).  Implicit path: against the oracle's LSODA at 1e-12 (same band as every
+    other topology) and, for blocks <= 3 sites, against the register kernel.  Explicit path: step-for-step against the oracle's RK45."""
     from phoskintime_amd.global_model import NetworkEngine, synthetic
-    from phoskintime_amd._capi import PhoskinError
     d = synthetic.make_network(N=5, total_sites=16, n_K=4, n_tf_edges=8, model=2, seed=9, max_sites=5)
     assert d["n_sites"].max() >= 4
     eng = NetworkEngine(**d)
@@ -448,6 +448,9 @@ def test_combinatorial_blocks_beyond_three_sites_through_the_explicit_integrator
     np.testing.assert_array_equal(eng.default_y0(), y0)
     Y, st, ns = eng.simulate_batch(X, t, rtol=1e-5, atol=1e-7, max_steps=2_000_000, method="dp5")
     assert not st.cpu().numpy().any()
+    Yw, stw, nsw = eng.simulate_batch(X, t)                      # Rosenbrock-W, defaults (1e-7 / 1e-9)
+    assert not stw.cpu().numpy().any()
+    band = lambda a, b: float(np.max(np.abs(a - b) / (1e-8 + 1e-6 * np.abs(b))))
     for k in range(2):
         nK, N, sites = 4, 5, 16
         x = X[k]
@@ -456,9 +459,19 @@ def test_combinatorial_blocks_beyond_three_sites_through_the_explicit_integrator
         Yo, acc, rej = nm.simulate_rk45(net, p, t, 1e-5, 1e-7, y0=y0, return_steps=True)
         np.testing.assert_allclose(Y[k].cpu().numpy(), Yo, rtol=1e-9, atol=1e-11)
         assert tuple(ns[k].cpu().numpy()) == (acc, rej)
-    with pytest.raises(PhoskinError):
-        eng.simulate_batch(X, t)                   # W-method: <= 3 sites per protein
+        truth = nm.simulate_odeint(net, p, t, 1e-12, 1e-12, 500000, y0=y0)
+        assert band(Yw[k].cpu().numpy(), truth) <= 0.5, (k, band(Yw[k].cpu().numpy(), truth))
     eng.close()
+    # <= 3 sites: the LDS kernel (linsolve = structured) and the register kernel implement the same scheme
+    g = np.load([x for x in GOLD if x.name == "network_m2_medium.npz"][0])
+    e3 = NetworkEngine.from_npz(g)
+    X3 = np.stack([_x(e3, g, k) for k in range(4)])
+    Ya, sa, na = e3.simulate_batch(X3, g["t_eval"], kernel="auto")
+    Yb, sb, nb = e3.simulate_batch(X3, g["t_eval"], kernel="lds")
+    assert not sa.cpu().numpy().any() and not sb.cpu().numpy().any()
+    assert band(Yb.cpu().numpy(), Ya.cpu().numpy()) <= 0.2
+    assert band(Yb.cpu().numpy()[:2], g["Y_tight"]) <= 0.5
+    e3.close()
 
 
 @pytest.mark.parametrize("model", [0, 2])
