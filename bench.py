@@ -9,11 +9,15 @@ Inputs are resident in HBM before the timed region.  Weak scaling: every rank ow
 
 Run:  python bench.py [--gpus N --steps K --warmup W]      (N > 1: under torch.distributed.run, one rank per GPU)
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline`, `cpu_baseline` and `parity`.
+
+Order of work on rank 0 at N = 1: (1) the CPU legs (cpu_baseline, cpu_same_algorithm, the single-call CPU latency) run FIRST, before this
+process makes its first GPU call -- they fork worker pools, and HIP does not support fork() after initialisation; (2) the timed region;
+(3) secondary, untimed-for-the-metric legs: peaks measured on this box, BASELINE config 1 as the reference runs it (one theta per call),
+BASELINE config 5's network path at the optimiser's tolerance, the other per-protein sizes.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -26,8 +30,66 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec sheet; 256 CU x 4 SIMD x 16 DFMA lanes/clk x 2 x 2.4 GHz)
+TGRID = np.array([0.0, 0.5, 0.75, 1.0, 2.0, 4.0, 8.0, 16.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
+
+
+def algorithmic_flops_per_step(n: int) -> int:
+    """FP64 flops one LRP12 step of the arrow (distributive) system NEEDS, counted from the algorithm, S = n + 2:
+    rhs 3n + 6, scaling S, factorisation 6n + 10, twelve solves 12 (4n + 6), accumulation of y_new and of the error estimate 46 S,
+    error norm 6 S.  Redundant work of a layout (shadowed rows, idle padding rows) is NOT counted: this is the numerator of a roofline."""
+    S = n + 2
+    return (3 * n + 6) + S + (6 * n + 10) + 12 * (4 * n + 6) + 46 * S + 6 * S
+
+
+def wait_for_library(lib_path: Path, local_rank: int):
+    """A checkout without the (git-ignored) library: local rank 0 builds it (hipcc is part of the image) and renames it into place
+    atomically; the others wait for the final name, with a bounded timeout and a clear error."""
+    if lib_path.exists():
+        return
+    if local_rank == 0:
+        import __graft_entry__ as graft
+        graft.build()
+        return
+    deadline = time.time() + 1500.0
+    while not lib_path.exists():
+        if time.time() > deadline:
+            raise SystemExit(f"rank {local_rank}: {lib_path} did not appear within 25 minutes (local rank 0's build failed?)")
+        time.sleep(1.0)
+
+
+def cpu_legs(args, theta_h, n_sites, S):
+    """Runs BEFORE the first GPU call of this process (fork-based worker pools)."""
+    from oracle import protein_models as pm
+    out = {}
+    cores = min(os.cpu_count() or 1, 16)
+    nsamp = args.cpu_sample or 128 * cores
+    rate, wall = pm.cpu_baseline(pm.DIST, n_sites, theta_h[:nsamp], np.ones(S), TGRID, cores)
+    out["cpu_baseline"] = {"value": rate, "unit": "replicas/s", "cores": cores, "kind": "port",
+                           "sample": "first %d replicas of the same batch; reference call shape (SciPy odeint/LSODA at default tolerances -> clip -> "
+                                     "flat) on the oracle's numpy-vectorised distmod RHS, one process per core; wall %.1f s.  The reference "
+                                     "itself runs this RHS Numba-compiled (absent from this image): expect it ~2x faster than this port" % (nsamp, wall)}
+    try:
+        from oracle import lrp8_cpu
+        nsamp2 = 2048 * cores
+        rate2 = lrp8_cpu.cpu_rate(theta_h[:nsamp2], n_sites, np.ones(S), TGRID, cores, stages=(8 if args.method == "lrp8" else 12), rtol=args.rtol, atol=args.atol)
+        out["cpu_same_algorithm"] = {"value": rate2, "unit": "replicas/s", "cores": cores, "kind": "port",
+                                     "sample": "first %d replicas; oracle/lrp8_dist.c (gcc -O2, scalar; %s at the same tolerances), one process per core" % (nsamp2, "LRP8" if args.method == "lrp8" else "LRP12")}
+    except Exception as e:
+        out["cpu_same_algorithm"] = {"error": repr(e)}
+    # BASELINE config 1 as the reference runs it: ONE distmod protein (4 sites), one theta per solve_ode call, on one core
+    try:
+        th1 = np.random.default_rng(20260515).uniform(0.05, 2.0, 12)
+        pm.solve_ode(pm.DIST, th1, np.ones(6), 4, TGRID)
+        t0 = time.perf_counter()
+        reps = 200
+        for _ in range(reps):
+            pm.solve_ode(pm.DIST, th1, np.ones(6), 4, TGRID)
+        out["config1_cpu_us"] = 1e6 * (time.perf_counter() - t0) / reps
+    except Exception as e:
+        out["config1_cpu_us"] = repr(e)
+    return out
 
 
 def main():
@@ -41,30 +103,33 @@ def main():
     ap.add_argument("--linsolve", default="auto")
     ap.add_argument("--method", default="lrp12")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-network", action="store_true", help="skip the secondary network-path measurement")
+    ap.add_argument("--no-network", action="store_true", help="skip the network-path leg (BASELINE config 5)")
+    ap.add_argument("--no-secondary", action="store_true", help="only the metric line (profiling runs)")
+    ap.add_argument("--only-network", action="store_true", help="only the network leg, printed as its own JSON line (one workload per rocprof profile)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="replicas in the CPU baseline sample (0 = 128 per core)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    # a checkout without the (git-ignored) library: local rank 0 builds it (hipcc is part of the image), the others wait for the file
-    lib_path = ROOT / "phoskintime_amd" / "libphoskin_hip.so"
-    if not lib_path.exists():
-        if local_rank == 0:
-            import __graft_entry__ as graft
-            graft.build()
-        else:
-            last = -1
-            for _ in range(1800):                         # wait until the file exists and has stopped growing
-                size = lib_path.stat().st_size if lib_path.exists() else -1
-                if size > 0 and size == last:
-                    break
-                last = size
-                time.sleep(2.0)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    wait_for_library(ROOT / "phoskintime_amd" / "libphoskin_hip.so", local_rank)
+    if args.rtol is None:
+        args.rtol = 1e-6 if args.method == "lrp12" else 1e-7
+    if args.atol is None:
+        args.atol = args.rtol * 1e-2
+
+    n_sites, S, P, T = 30, 32, 64, TGRID.size
+    B = args.replicas
+    rng = np.random.default_rng(20260515 + 2 + 7919 * rank)          # rank 0 == the seed of tests/golden/*_c3bounds.npz
+    theta_h = rng.uniform(0.0, 20.0, (B, P))
+
+    # ---- (1) CPU legs: before the first GPU call of this process
+    cpu = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only_network:
+        cpu = cpu_legs(args, theta_h, n_sites, S)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -77,17 +142,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from phoskintime_amd import batch, _capi
-
-    model, n_sites = _capi.DIST, 30
-    S, P = batch.n_states(model, n_sites), batch.n_params(model, n_sites)
-    B = args.replicas
-    tgrid = np.array([0.0, 0.5, 0.75, 1.0, 2.0, 4.0, 8.0, 16.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
-    T = tgrid.size
-    rng = np.random.default_rng(20260515 + 2 + 7919 * rank)          # rank 0 == the seed of tests/golden/*_c3bounds.npz
-    theta_h = rng.uniform(0.0, 20.0, (B, P))
+    if args.only_network:
+        print(json.dumps({"network_config5": network_leg(dev)}), flush=True)
+        return
+    model = _capi.DIST
+    assert (batch.n_states(model, n_sites), batch.n_params(model, n_sites)) == (S, P)
     theta = torch.as_tensor(theta_h, device=dev)
     y0 = torch.ones(S, dtype=torch.float64, device=dev)
-    tt = torch.as_tensor(tgrid, device=dev)
+    tt = torch.as_tensor(TGRID, device=dev)
+
     # two result sets, used alternately: the all-gather of step i runs on its own HIP stream while step i + 1 computes into the other set
     def new_out():
         return batch.BatchResult(sol=torch.empty((B, T, S), dtype=torch.float64, device=dev), flat=None,
@@ -96,10 +159,6 @@ def main():
                                  n_steps=torch.zeros((B, 2), dtype=torch.int32, device=dev))
     outs = [new_out(), new_out()] if use_dist else [new_out()]
     out = outs[0]
-    if args.rtol is None:
-        args.rtol = 1e-6 if args.method == "lrp12" else 1e-7
-    if args.atol is None:
-        args.atol = args.rtol * 1e-2
     kw = dict(want_flat=False, metric="total_signal", method=args.method, linsolve=args.linsolve, rtol=args.rtol, atol=args.atol)
     main_stream = torch.cuda.current_stream(dev)
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
@@ -163,6 +222,8 @@ def main():
         value = total_replicas / elapsed
         bytes_per_replica = 8 * (P + S + T * S)                      # read theta and y0, write sol[T,S]
         achieved = B * bytes_per_replica / (kernel_ms * 1e-3) / 1e9
+        kname = {"lrp12": "pk::dist_fast_kernel<4, 8, 5, true, 2>", "lrp8": "pk::dist_fast_kernel<8, 4, 3, false, 1>",
+                 "rodas4": "pk::dist_fast_kernel<8, 4, 0, false, 1>"}.get(args.method, "see config") if args.linsolve == "auto" else "see config"
         res = {
             "metric": "ODE-solve replicas/sec (32-state distributive, 14 tp)", "value": value, "unit": "replicas/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -173,22 +234,31 @@ def main():
                                                                "; 1 RCCL all-gather of Y per step" if use_dist else ""),
                        "replicas_per_gpu": B, "n_states": S, "n_params": P, "n_timepoints": T, "method": args.method,
                        "parallelism": "replica-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": {"lrp12": "pk::dist_fast_kernel<4, 8, 5, true, 2>", "lrp8": "pk::dist_fast_kernel<8, 4, 3, false, 1>", "rodas4": "pk::dist_fast_kernel<8, 4, 0, false, 1>"}.get(args.method, "see config") if args.linsolve == "auto" else "see config", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_replica": bytes_per_replica,
-                         "note": "path is FP64 VALU-issue bound, not HBM bound (DESIGN.md); HBM fraction reported as the contract asks"},
+                         "algorithmic_bytes_per_launch": B * bytes_per_replica,
+                         "note": "path is FP64 VALU-issue bound, not HBM bound (DESIGN.md); HBM fraction reported as the contract asks; "
+                                 "the binding roofline is `roofline_fp64`"},
             "solver": {"mean_accepted_steps": nst[0], "mean_rejected_steps": nst[1], "flagged_replicas": status_bad},
         }
-        # HBM traffic of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh)
-        pmc = ROOT / "profiles" / ("r01_k_final_pmc.json" if args.method == "lrp12" else "r01_g_dist_fast_lrp8_pmc.json")
-        if pmc.exists() and args.method in ("lrp12", "lrp8") and args.linsolve == "auto" and B == 65536 and (args.rtol, args.atol) == ((1e-6, 1e-8) if args.method == "lrp12" else (1e-7, 1e-9)):
-            pj = json.loads(pmc.read_text())
-            res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
-            res["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)" % pmc.name
-            res["roofline"]["algorithmic_bytes_per_launch"] = B * bytes_per_replica
-            # the binding resource: VALU issue.  f64 VALU ops take 4 cycles per wave64 on a SIMD (16 lanes / clk)
-            res["valu_issue"] = {"valu_insts_per_launch": pj["SQ_INSTS_VALU"], "lds_insts_per_launch": pj["SQ_INSTS_LDS"],
-                                 "busy_frac_at_4clk_2p1GHz": pj["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.1e9 * kernel_ms * 1e-3),
-                                 "note": "1024 SIMDs; clock under FP64 load ~2.1 GHz; counters from the same PMC run"}
+        # the binding roofline: FP64 vector arithmetic.  Numerator = flops the ALGORITHM needs (counted per step, times the steps the
+        # kernel reports), never the instructions a layout happens to execute
+        fl_step = algorithmic_flops_per_step(n_sites)
+        fl_launch = B * fl_step * (nst[0] + nst[1])
+        res["roofline_fp64"] = {"bound": "fp64_valu", "achieved": fl_launch / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl_launch / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, "algorithmic_flops_per_step": fl_step,
+                                "algorithmic_flops_per_launch": fl_launch, "peak_source": "spec sheet; measured value under peaks_measured"}
+        # counters of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh): labelled as such,
+        # and only attached when the run matches the profiled configuration
+        prof = sorted((ROOT / "profiles").glob("r02_*_config3_pmc.json")) or sorted((ROOT / "profiles").glob("r01_k_final_pmc.json"))
+        if prof and args.method == "lrp12" and args.linsolve == "auto" and B == 65536 and (args.rtol, args.atol) == (1e-6, 1e-8):
+            pj = json.loads(prof[-1].read_text())
+            if pj.get("kernel") == kname:
+                res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = "committed profile profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 correction); not re-measured in this run" % prof[-1].name
+                res["valu_issue"] = {"valu_insts_per_launch": pj["SQ_INSTS_VALU"], "lds_insts_per_launch": pj["SQ_INSTS_LDS"],
+                                     "busy_frac_at_4clk_2p1GHz": pj["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.1e9 * kernel_ms * 1e-3),
+                                     "note": "instruction counts from the committed profile %s, kernel time from this run; 1024 SIMDs, ~2.1 GHz under FP64 load" % prof[-1].name}
         # parity on the first 64 replicas of this very batch against the committed SciPy reference trajectories
         gfile = ROOT / "tests" / "golden" / "protein_distmod_n30_c3bounds.npz"
         if gfile.exists() and args.method in ("rodas4", "lrp8", "lrp12") and B >= 64:
@@ -201,69 +271,134 @@ def main():
                                  "max_abs_dy_vs_scipy_default": float(np.max(np.abs(sol64 - g["sol_default"]))),
                                  "reference_default_vs_tight_band": float(np.max(np.abs(g["sol_default"] - tight) / (1e-8 + 1e-6 * np.abs(tight)))),
                                  "n": 64, "band": "rtol 1e-6 / atol 1e-8"}
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import protein_models as pm
-            cores = min(os.cpu_count() or 1, 16)
-            nsamp = args.cpu_sample or 128 * cores
-            rate, wall = pm.cpu_baseline(model, n_sites, theta_h[:nsamp], np.ones(S), tgrid, cores)
-            res["cpu_baseline"] = {"value": rate, "unit": "replicas/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d replicas of the same batch; reference call shape (SciPy odeint/LSODA at default "
-                                             "tolerances -> clip -> flat) on the oracle's numpy-vectorised distmod RHS, one process per core; "
-                                             "wall %.1f s" % (nsamp, wall)}
-        if not args.no_cpu_baseline and world == 1:
-            # the SAME algorithm (LRP12 / LRP8 + arrow elimination) in scalar C on the host cores: separates what the method buys from what the GPU buys
-            try:
-                from oracle import lrp8_cpu
-                cores = min(os.cpu_count() or 1, 16)
-                nsamp2 = 2048 * cores
-                rate2 = lrp8_cpu.cpu_rate(theta_h[:nsamp2], n_sites, np.ones(S), tgrid, cores, stages=(8 if args.method == "lrp8" else 12),
-                                          rtol=args.rtol, atol=args.atol)
-                res["cpu_same_algorithm"] = {"value": rate2, "unit": "replicas/s", "cores": cores, "kind": "port",
-                                             "sample": "first %d replicas; oracle/lrp8_dist.c (gcc -O2, scalar; %s at the same tolerances), one process per core" % (nsamp2, "LRP8" if args.method == "lrp8" else "LRP12")}
-            except Exception as e:
-                res["cpu_same_algorithm"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and world == 1 and not args.no_network:
-            # secondary evidence (NOT the metric): the network path of BASELINE configs 4 / 5 on a synthetic network of their shape
-            try:
-                from phoskintime_amd.global_model import NetworkEngine, synthetic
-                net = synthetic.make_network(model=0)
-                eng = NetworkEngine(**net)
-                Xn = torch.as_tensor(synthetic.random_candidates(net, 8192, seed=1), device=dev)
-                tn = np.unique(np.concatenate([net["kin_grid"], [15.0]]))
-                eng.simulate_batch(Xn[:256], tn, rtol=1e-5, atol=1e-7); torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                Yn, stn, nsn = eng.simulate_batch(Xn, tn, rtol=1e-5, atol=1e-7); torch.cuda.synchronize(dev)
-                dtn = time.perf_counter() - t1
-                res["network_secondary"] = {"workload": "synthetic config-5-shaped network (N=100 proteins, 300 sites, S=500 states, n_var=841), "
-                                                        "8192 candidates, simulate at the reference's sensitivity tolerance rtol 1e-5 / atol 1e-7",
-                                            "candidates_per_s": 8192 / dtn, "ms": 1e3 * dtn, "mean_steps": float(nsn[:, 0].double().mean()),
-                                            "flagged": int((stn != 0).sum()), "integrator": "ROS34PW2 Rosenbrock-W, block-diagonal Jacobian"}
-                eng.close()
-            except Exception as e:  # never let the secondary line break the metric
-                res["network_secondary"] = {"error": repr(e)}
-            # secondary evidence (NOT the metric): the other per-protein configurations BASELINE.json lists, at their sizes
-            try:
-                other = {}
-                for label, mdl, nn, Bo in (("config1_size_distmod_n4_B65536", "distmod", 4, 65536), ("config2_succmod_n14_B4096", "succmod", 14, 4096),
-                                           ("config2_size_succmod_n14_B65536", "succmod", 14, 65536), ("randmod_n4_B65536", "randmod", 4, 65536)):
-                    Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
-                    tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.0, 20.0, (Bo, Po)), device=dev)
-                    oo = batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False)
-                    for _ in range(50):
-                        batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
-                    torch.cuda.synchronize(dev)
-                    t1 = time.perf_counter()
-                    for _ in range(200):
-                        batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
-                    torch.cuda.synchronize(dev)
-                    dto = (time.perf_counter() - t1) / 200
-                    other[label] = {"replicas_per_s": Bo / dto, "ms": 1e3 * dto, "flagged": int((oo.status != 0).sum())}
-                res["other_protein_configs"] = other
-            except Exception as e:
-                res["other_protein_configs"] = {"error": repr(e)}
+        for k in ("cpu_baseline", "cpu_same_algorithm"):
+            if k in cpu:
+                res[k] = cpu[k]
+        if world == 1 and not args.no_secondary:
+            res.update(secondary_legs(args, dev, tt, cpu))
+            if res.get("peaks_measured", {}).get("fp64_fma_tflops", 0) > 0:
+                res["roofline_fp64"]["frac_of_measured_peak"] = res["roofline_fp64"]["achieved"] / res["peaks_measured"]["fp64_fma_tflops"]
+            if res.get("peaks_measured", {}).get("hbm_copy_gbs", 0) > 0:
+                res["roofline"]["frac_of_measured_peak"] = achieved / res["peaks_measured"]["hbm_copy_gbs"]
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def network_leg(dev):
+    """BASELINE config 5's path at the reference's OPTIMISATION tolerance (rtol = atol = 1e-8, config.toml:403-404): 8 192 candidates of an
+    N = 100 network through simulate + objective.  The network is the reference-built one of tests/golden/netlarge_m0.npz when present
+    (candidate 0 = its parameter set 0, so the band error against the reference's LSODA@1e-12 trajectory is part of the line)."""
+    from phoskintime_amd.global_model import NetworkEngine, synthetic
+    from phoskintime_amd.global_model.optproblem import GlobalODEBatch
+    gfile = ROOT / "tests" / "golden" / "netlarge_m0.npz"
+    Bn = 8192
+    rngn = np.random.default_rng(20260515 + 4)
+    if gfile.exists():
+        g = np.load(gfile)
+        eng = NetworkEngine.from_npz(g)
+        base = eng.pack_params(g["c_k"][0], g["A_i"][0], g["B_i"][0], g["C_i"][0], g["D_i"][0], g["Dp_i"][0], g["E_i"][0], g["tf_scale"][0])
+        tn = g["t_eval"]; src = "reference-built network of tests/golden/netlarge_m0.npz"
+    else:
+        g = None
+        net = synthetic.make_network(model=0)
+        eng = NetworkEngine(**net)
+        base = synthetic.default_candidate(net)
+        tn = np.unique(np.concatenate([net["kin_grid"], [15.0]])); src = "synthetic network (fixture absent)"
+    X = base[None, :] * np.exp(0.5 * rngn.standard_normal((Bn, base.size)))
+    X[0] = base
+    Xraw = np.log(np.expm1(np.maximum(X, 1e-12)))                       # raw decision vectors (inverse softplus), as the optimiser holds them
+    Xd = torch.as_tensor(Xraw, device=dev)
+    lists, ld = eng.make_index_lists(tn, tn, tn[tn >= 4.0], tn)         # every protein / site at every time of its modality
+    eng.free_loss(lists)
+    for k in ("obs_prot", "obs_rna", "obs_pho"):
+        ld[k] = np.abs(1.0 + 0.05 * rngn.standard_normal(ld[k].size))
+    sl = {"c_k": None}
+    defaults = dict(zip(("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i"), np.split(base[:-1], np.cumsum([eng.n_K, eng.N, eng.N, eng.N, eng.N, eng.total_sites])))); defaults["tf_scale"] = float(base[-1])
+    prob = GlobalODEBatch(eng, sl, ld, defaults, {"protein": 1.0, "rna": 1.0, "phospho": 1.0, "prior": 0.01}, tn, rtol=1e-8, atol=1e-8)
+    prob.evaluate_device(Xd[:256]); torch.cuda.synchronize(dev)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    st = torch.cuda.current_stream(dev)
+    t1 = time.perf_counter()
+    e0.record(st)
+    Y, status, nsn = eng.simulate_batch(Xd, tn, raw=True, rtol=1e-8, atol=1e-8, max_steps=prob.max_steps * tn.size)
+    e1.record(st)
+    _, F = eng.objective_batch(prob.loss, Y, loss_mode=0, x=Xd, raw=True, defaults=prob.defaults, lambdas=prob.lam, status=status)
+    e2.record(st)
+    torch.cuda.synchronize(dev)
+    dtn = time.perf_counter() - t1
+    steps = nsn.double().mean(dim=0).tolist()
+    out = {"workload": "BASELINE config 5 shape: 8192 raw decision vectors (defaults x log-normal 0.5), %s: N=%d proteins, %d sites, S=%d states, "
+                       "n_var=%d; simulate at rtol=atol=1e-8 (config.toml:403-404) on the %d-point grid + fused 3-objective loss" % (src, eng.N, eng.total_sites, eng.S, eng.n_var, tn.size),
+           "candidates_per_s": Bn / dtn, "wall_ms": 1e3 * dtn, "simulate_kernel_ms": e0.elapsed_time(e1), "objective_kernel_ms": e1.elapsed_time(e2),
+           "mean_accepted_steps": steps[0], "mean_rejected_steps": steps[1], "flagged": int((status != 0).sum()),
+           "integrator": "ROS34PW2 Rosenbrock-W, per-protein block Jacobian",
+           "algorithmic_bytes_per_candidate": 8 * (eng.n_var + eng.S + 3), "hbm_gbs_algorithmic": Bn * 8 * (eng.n_var + eng.S + 3) / (e0.elapsed_time(e1) * 1e-3) / 1e9,
+           "finite_objectives": bool(torch.isfinite(F).all())}
+    if g is not None:
+        truth = g["Y_tight"][0]; y0c = Y[0].cpu().numpy()
+        out["band_err_candidate0_vs_reference_lsoda_1e-12"] = float(np.max(np.abs(y0c - truth) / (1e-8 + 1e-6 * np.abs(truth))))
+        out["reference_lsoda_1e-8_band_vs_its_1e-12"] = float(np.max(np.abs(g["Y_lsoda8"][0] - truth) / (1e-8 + 1e-6 * np.abs(truth))))
+    prob.close(); eng.close()
+    return out
+
+
+def secondary_legs(args, dev, tt, cpu):
+    """Evidence beside the metric (never the metric): machine peaks measured here, config 1 latency, config 5 network path, other sizes."""
+    from phoskintime_amd import batch, models
+    res = {}
+    ctx = batch.get_context()
+    try:
+        res["peaks_measured"] = {"hbm_copy_gbs": ctx.lib.pk_measure_hbm_gbs(ctx.handle, 2 << 30, 10), "fp64_fma_tflops": ctx.lib.pk_measure_fp64_fma_tflops(ctx.handle, 1 << 16),
+                                 "spec": {"hbm_gbs": HBM_PEAK_GBS, "fp64_valu_tflops": FP64_VALU_PEAK_TFLOPS},
+                                 "how": "pk_measure_hbm_gbs: 10 copies of 2 GiB (read + written bytes / time); pk_measure_fp64_fma_tflops: 16 independent v_fma_f64 chains per lane, 4 waves per SIMD"}
+    except Exception as e:
+        res["peaks_measured"] = {"error": repr(e)}
+    # BASELINE config 1 as the reference runs it: one distmod protein, ONE theta per call, through the drop-in models.solve_ode
+    try:
+        models.set_model("distmod")
+        th1 = np.random.default_rng(20260515).uniform(0.05, 2.0, 12)
+        y01 = np.ones(6)
+        for _ in range(50):
+            models.solve_ode(th1, y01, 4, TGRID)
+        lat = []
+        for _ in range(500):
+            t1 = time.perf_counter(); models.solve_ode(th1, y01, 4, TGRID); lat.append(time.perf_counter() - t1)
+        lat = np.sort(np.array(lat)) * 1e6
+        res["config1_single_call"] = {"workload": "BASELINE config 1: models.distmod, 4 sites, 14 time points, ONE theta per models.solve_ode call (host arrays in, host arrays out)",
+                                      "gpu_us_median": float(lat[lat.size // 2]), "gpu_us_p90": float(lat[int(0.9 * lat.size)]), "gpu_us_min": float(lat[0]),
+                                      "cpu_port_us": cpu.get("config1_cpu_us"), "workspace": ctx.workspace_stats(),
+                                      "note": "one call = pack into the page-locked buffer -> 1 H2D -> kernel (1 workgroup) -> 1 D2H -> sync; no hipMalloc / hipFree"}
+        models.set_model("randmod")
+    except Exception as e:
+        res["config1_single_call"] = {"error": repr(e)}
+    if not args.no_network:
+        try:
+            res["network_config5"] = network_leg(dev)
+        except Exception as e:  # never let a secondary line break the metric
+            res["network_config5"] = {"error": repr(e)}
+    try:
+        other = {}
+        for label, mdl, nn, Bo in (("config1_size_distmod_n4_B65536", "distmod", 4, 65536), ("config2_succmod_n14_B4096", "succmod", 14, 4096),
+                                   ("config2_size_succmod_n14_B65536", "succmod", 14, 65536), ("randmod_n4_B65536", "randmod", 4, 65536),
+                                   ("wide_distmod_n100_B4096", "distmod", 100, 4096), ("wide_succmod_n100_B4096", "succmod", 100, 4096), ("wide_randmod_n7_B1024", "randmod", 7, 1024)):
+            Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
+            tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.0, 20.0, (Bo, Po)), device=dev)
+            oo = batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False)
+            reps = 5 if label.startswith("wide") else 200
+            for _ in range(max(1, reps // 4)):
+                batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
+            torch.cuda.synchronize(dev)
+            dto = (time.perf_counter() - t1) / reps
+            other[label] = {"replicas_per_s": Bo / dto, "ms": 1e3 * dto, "flagged": int((oo.status != 0).sum()), "mean_steps": float(oo.n_steps[:, 0].double().mean())}
+        res["other_protein_configs"] = other
+    except Exception as e:
+        res["other_protein_configs"] = {"error": repr(e)}
+    return res
 
 
 if __name__ == "__main__":

@@ -257,6 +257,12 @@ double pk_time_solve_protein_batch(pk_ctx*, int iters, int model, int n_sites, i
                                    double* sol, double* flat, double* metric, int metric_id,
                                    int32_t* status, int32_t* n_steps);
 
+/* Machine peaks measured on the context's GPU, for bench.py's roofline fractions (the spec-sheet values are printed beside them):
+ * sustained HBM copy rate in GB/s (read + written bytes; `bytes` >= 1 MiB per buffer, choose it well beyond the 256 MiB Infinity Cache)
+ * and sustained FP64 vector FMA rate in TFLOP/s.  Both allocate and free their own buffers; < 0 on error. */
+double pk_measure_hbm_gbs(pk_ctx*, int64_t bytes, int iters);
+double pk_measure_fp64_fma_tflops(pk_ctx*, int iters);
+
 #ifdef __cplusplus
 }
 #endif

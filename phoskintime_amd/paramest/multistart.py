@@ -2,8 +2,9 @@
 
 The reference runs 24-48 independent ``scipy.optimize.curve_fit`` (TRF, ``x_scale='jac'``) calls; each TRF iteration costs 1 + P
 ``solve_ode`` calls for a 2-point finite-difference Jacobian, one at a time.  Here ALL starts advance in lockstep: every
-iteration is ONE launch of ``n_active * (1 + P)`` replicas (``solve_ode_batch`` returning the ``flat`` observable vectors), the
-small dense algebra (P <= 64) stays on the host.
+iteration is ONE launch of ``n_active * P`` perturbed replicas; residuals, Jacobian columns and the normal equations J^T J / J^T r
+are formed on the GPU from the ``flat`` vectors the kernel wrote, and only P x P + P doubles per row return to the host, where the small
+bounded-LM algebra (P <= 64) runs batched.
 
 * start points: same construction and the same NumPy RNG stream as the reference (base, n/3 Gaussian jitters of 10 % of the
   range, stratified uniform for the rest; seed + hash(gene)), so a given (gene, seed) yields the reference's start list;
@@ -62,13 +63,14 @@ class RowsFit:
     p: np.ndarray               # [R, P] final parameters (fitted space)
     cost: np.ndarray            # [R] 0.5 * ||r||^2
     r: np.ndarray               # [R, Nr] final weighted residuals
-    J: np.ndarray               # [R, Nr, P] last Jacobian of the weighted residuals
+    JTJ: np.ndarray             # [R, P, P] J^T J of the weighted residuals at the last Jacobian evaluation (what pcov needs)
     n_iter: int
     n_solves: int
+    n_launches: int = 0         # solve launches (Jacobian batches + trial batches)
 
 
 def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None,
-                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, **solver_kw) -> RowsFit:
+                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra: bool = True, **solver_kw) -> RowsFit:
     """R independent bounded least-squares problems in lockstep: row k fits ``[flat(p) ; lam_k / P * p**2]`` to ``[target_k ; 0]`` with
     weights ``sigma_k`` from the start point ``P0[k]``.  Rows may be the starts of one multistart fit, the (lambda, weight) grid of
     ``find_best_lambda``, bootstrap replicates, different proteins of the same size -- or any mix.
@@ -76,8 +78,12 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     P0 [R, P]; init_cond [S] or [R, S]; target [Nd] or [R, Nd]; sigma None, [Nr] or [R, Nr] with Nr = Nd (+ P when any lam > 0);
     lam scalar or [R]; bounds (lb, ub), each [P] or [R, P].
 
-    Every iteration is ONE launch for the forward-difference Jacobians (n_active * P replicas) plus one launch per damping round
-    for the trial points; the P x P algebra of all rows is batched numpy on the host."""
+    Every iteration is ONE launch for the Jacobian columns (n_active * P replicas) plus one launch per damping round for the trial
+    points.  ``device_algebra=True`` (default): residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU
+    (torch ops on the `flat` tensors the kernel wrote); per iteration and row only P x P + P doubles come back and a P-vector of trial
+    parameters goes up -- round 1 moved every ``flat`` vector (n_active * (1 + P) x Nd doubles) over PCIe per iteration.  The P x P
+    bounded Levenberg-Marquardt algebra itself stays batched numpy on the host.  ``device_algebra=False`` is the round-1 path (A/B)."""
+    import torch
     log_space = (model == "randmod")
     P0 = np.atleast_2d(np.asarray(P0, float))
     R, P = P0.shape
@@ -94,30 +100,49 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         sig = np.broadcast_to(sig, (R, sig.shape[-1])) if sig.ndim == 1 else sig
         if sig.shape[1] != Nr:
             raise ValueError(f"sigma must hold {Nr} entries")
-    tfull = np.concatenate([tgt, np.zeros((R, P))], axis=1) if use_reg else tgt
+    tfull = np.concatenate([tgt, np.zeros((R, P))], axis=1) if use_reg else np.array(tgt, dtype=float, copy=True)
     lb, ub = (np.broadcast_to(np.asarray(b, float), (R, P)) for b in bounds)
     y0 = np.asarray(init_cond, float)
     y0_rows = y0.ndim == 2
     n_solves = 0
+    n_launches = 0
+    dev = torch.device("cuda", batch.get_context().device)
+    if device_algebra:
+        t_d = torch.as_tensor(tfull, device=dev); isig_d = torch.as_tensor(1.0 / sig, device=dev); lam_d = torch.as_tensor(lam / P, device=dev)
+        y0_d = torch.as_tensor(np.array(y0, dtype=float, copy=True), device=dev)
+
+    def residuals_dev(Pm_d, rows_d):
+        """Pm_d [m, P] (GPU) for the problems rows_d [m] (GPU index tensor) -> weighted residuals [m, Nr] on the GPU (one launch)."""
+        nonlocal n_solves, n_launches
+        theta = torch.exp(Pm_d) if log_space else Pm_d
+        flat = batch.solve_ode_batch(model, theta, y0_d[rows_d] if y0_rows else y0_d, num_psites, time_points, want_sol=False, want_flat=True, **solver_kw).flat
+        n_solves += Pm_d.shape[0]; n_launches += 1
+        f = torch.cat([flat, lam_d[rows_d, None] * Pm_d * Pm_d], dim=1) if use_reg else flat
+        rr = (f - t_d[rows_d]) * isig_d[rows_d]
+        return torch.where(torch.isfinite(rr), rr, torch.full_like(rr, 1e6))            # failed solves are very bad, not fatal
 
     def residuals(Pm, rows):
-        """Pm [m, P] for the problems `rows` [m] -> weighted residuals [m, Nr]  (one launch)."""
-        nonlocal n_solves
+        """Host path: Pm [m, P] for the problems `rows` [m] -> weighted residuals [m, Nr]  (one launch, flat over PCIe)."""
+        nonlocal n_solves, n_launches
         theta = np.exp(Pm) if log_space else Pm
         flat = batch.solve_ode_batch(model, theta, y0[rows] if y0_rows else y0, num_psites, time_points, want_sol=False, want_flat=True,
                                      **solver_kw).flat.cpu().numpy()
-        n_solves += Pm.shape[0]
+        n_solves += Pm.shape[0]; n_launches += 1
         f = np.concatenate([flat, (lam[rows, None] / P) * Pm ** 2], axis=1) if use_reg else flat
         rr = (f - tfull[rows]) / sig[rows]
-        return np.where(np.isfinite(rr), rr, 1e6)            # failed solves are very bad, not fatal
+        return np.where(np.isfinite(rr), rr, 1e6)
 
     p = np.clip(P0, lb, ub)
     allr = np.arange(R)
-    r = residuals(p, allr)
-    cost = 0.5 * np.sum(r * r, axis=1)
+    if device_algebra:
+        r_d = residuals_dev(torch.as_tensor(p, device=dev), torch.as_tensor(allr, device=dev))
+        cost = (0.5 * (r_d * r_d).sum(dim=1)).cpu().numpy()
+    else:
+        r = residuals(p, allr)
+        cost = 0.5 * np.sum(r * r, axis=1)
     mu = np.full(R, 1e-3)
     active = np.ones(R, bool)
-    J = np.zeros((R, Nr, P))
+    JTJ = np.zeros((R, P, P))
     it = 0
     for it in range(1, max_iter + 1):
         idx = np.where(active)[0]
@@ -128,11 +153,18 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         h = np.where(p[idx] + h > ub[idx], -h, h)
         Pp = np.repeat(p[idx], P, axis=0)
         Pp[np.arange(idx.size * P), np.tile(np.arange(P), idx.size)] += h.reshape(-1)
-        rp = residuals(Pp, np.repeat(idx, P)).reshape(idx.size, P, Nr)
-        J[idx] = np.transpose((rp - r[idx][:, None, :]) / h[:, :, None], (0, 2, 1))
-        Ja = J[idx]
-        g = np.einsum("knp,kn->kp", Ja, r[idx])
-        A = np.einsum("knp,knq->kpq", Ja, Ja)
+        if device_algebra:
+            idx_d = torch.as_tensor(idx, device=dev)
+            rp = residuals_dev(torch.as_tensor(Pp, device=dev), idx_d.repeat_interleave(P)).reshape(idx.size, P, Nr)
+            Jd = ((rp - r_d[idx_d][:, None, :]) / torch.as_tensor(h, device=dev)[:, :, None]).transpose(1, 2)        # [k, Nr, P]
+            A = torch.bmm(Jd.transpose(1, 2), Jd).cpu().numpy()                                                     # J^T J : [k, P, P]
+            g = torch.bmm(Jd.transpose(1, 2), r_d[idx_d][:, :, None])[:, :, 0].cpu().numpy()                        # J^T r : [k, P]
+        else:
+            rp = residuals(Pp, np.repeat(idx, P)).reshape(idx.size, P, Nr)
+            Ja = np.transpose((rp - r[idx][:, None, :]) / h[:, :, None], (0, 2, 1))
+            g = np.einsum("knp,kn->kp", Ja, r[idx])
+            A = np.einsum("knp,knq->kpq", Ja, Ja)
+        JTJ[idx] = A
         free = ~(((p[idx] <= lb[idx]) & (g > 0)) | ((p[idx] >= ub[idx]) & (g < 0)))
         gfree = np.where(free, g, 0.0)
         done = (~free.any(axis=1)) | (np.linalg.norm(gfree, axis=1) < 1e-14 * np.maximum(1.0, cost[idx]))
@@ -161,8 +193,13 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
                         pass
             step = np.where(np.isfinite(step), step, 0.0)
             trial = np.clip(p[rows] + step, lb[rows], ub[rows])
-            rn = residuals(trial, rows)
-            cn = 0.5 * np.sum(rn * rn, axis=1)
+            if device_algebra:
+                rows_d = torch.as_tensor(rows, device=dev)
+                rn_d = residuals_dev(torch.as_tensor(trial, device=dev), rows_d)
+                cn = (0.5 * (rn_d * rn_d).sum(dim=1)).cpu().numpy()
+            else:
+                rn = residuals(trial, rows)
+                cn = 0.5 * np.sum(rn * rn, axis=1)
             dp = trial - p[rows]
             pred = -(np.einsum("kp,kp->k", g[pend], dp) + 0.5 * np.einsum("kp,kpq,kq->k", dp, A[pend], dp))
             rho = np.where(pred > 0, (cost[rows] - cn) / np.where(pred > 0, pred, 1.0), -1.0)
@@ -170,19 +207,60 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
             dx = np.linalg.norm(dp, axis=1); dc = cost[rows] - cn
             conv = ok & ((dc <= ftol * np.maximum(cn, 1e-300)) | (dx <= xtol * (xtol + np.linalg.norm(trial, axis=1))))
             acc = rows[ok]
-            p[acc], r[acc], cost[acc] = trial[ok], rn[ok], cn[ok]
+            p[acc], cost[acc] = trial[ok], cn[ok]
+            if device_algebra:
+                if acc.size:
+                    r_d[rows_d[torch.as_tensor(ok, device=dev)]] = rn_d[torch.as_tensor(ok, device=dev)]
+            else:
+                r[acc] = rn[ok]
             mu[acc] = np.maximum(mu[acc] * np.where(rho[ok] > 0.75, 1.0 / 3.0, 1.0), 1e-12)
             active[rows[conv]] = False
             mu[rows[~ok]] *= 4.0
             pend = pend[~ok]
         active[idx[pend]] = False          # no acceptable step within the damping budget: converged / stalled
-    return RowsFit(p=p, cost=cost, r=r, J=J, n_iter=it, n_solves=n_solves)
+    r_out = r_d.cpu().numpy() if device_algebra else r
+    return RowsFit(p=p, cost=cost, r=r_out, JTJ=JTJ, n_iter=it, n_solves=n_solves, n_launches=n_launches)
 
 
-def _pcov(Jb, cost_b, absolute_sigma):
-    Nr, P = Jb.shape
+def fit_rows_sharded(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None, **kw) -> RowsFit:
+    """``fit_rows_batch`` with the R problems block-partitioned over the ranks of an initialised ``torch.distributed`` group (one process
+    per GPU): every rank fits its rows, then ONE all-gather of the per-row results [p | cost | J^T J] (P + 1 + P^2 doubles per row) gives
+    every rank the complete ``RowsFit``.  Rows never interact, so the result equals the single-GPU fit row for row.  Without a process
+    group (or at world size 1) it is ``fit_rows_batch``."""
+    import torch
+    from ..distributed import shard_bounds, all_gather_replicas, _world, _control_device
+    rank, world = _world()
+    P0 = np.atleast_2d(np.asarray(P0, float))
+    R, P = P0.shape
+    if world == 1:
+        return fit_rows_batch(model, num_psites, time_points, P0, init_cond, target, sigma=sigma, lam=lam, bounds=bounds, **kw)
+    lo, hi = shard_bounds(R, rank, world)
+    rows = lambda a, nd: (np.asarray(a, float)[lo:hi] if np.asarray(a).ndim == nd else a)       # per-row arguments are sliced, shared ones passed on
+    dev = _control_device()                                        # HBM for RCCL, host memory for the gloo tests
+    if hi > lo:
+        fit = fit_rows_batch(model, num_psites, time_points, P0[lo:hi], rows(init_cond, 2), rows(target, 2), sigma=(None if sigma is None else rows(sigma, 2)),
+                             lam=rows(lam, 1), bounds=tuple(rows(b, 2) for b in bounds), **kw)
+        Nr = fit.r.shape[1]
+        packed = np.concatenate([fit.p, fit.cost[:, None], fit.JTJ.reshape(hi - lo, P * P), fit.r], axis=1)
+        meta = (fit.n_iter, fit.n_solves, fit.n_launches)
+    else:
+        Nr = 0
+        packed = np.zeros((0, 0)); meta = (0, 0, 0)
+    # every rank must offer the same row width: the residual length is known from the shapes alone
+    Nd = np.asarray(target).shape[-1]
+    Nr = Nd + (P if np.any(np.asarray(lam, float) > 0.0) else 0)
+    if packed.shape[0] == 0:
+        packed = np.zeros((0, P + 1 + P * P + Nr))
+    full = all_gather_replicas(torch.as_tensor(packed, device=dev), R).cpu().numpy()
+    return RowsFit(p=full[:, :P], cost=full[:, P], JTJ=full[:, P + 1:P + 1 + P * P].reshape(R, P, P), r=full[:, P + 1 + P * P:], n_iter=meta[0], n_solves=meta[1],
+                   n_launches=meta[2])
+
+
+def _pcov(JTJ_b, cost_b, absolute_sigma, Nr):
+    """(J^T J)^-1 [* s^2] as scipy.optimize.curve_fit reports it."""
+    P = JTJ_b.shape[0]
     try:
-        pcov = np.linalg.inv(Jb.T @ Jb)
+        pcov = np.linalg.inv(JTJ_b)
         if not absolute_sigma and Nr > P:
             pcov = pcov * (2.0 * cost_b / (Nr - P))
         return pcov
@@ -211,7 +289,7 @@ def curve_fit_multistart_batch(model: str, init_cond, num_psites: int, time_poin
     # score every start like the reference (solve at popt, score_fit against the un-regularised target) and keep the best
     scores = _scores(model, fit.p, init_cond, num_psites, time_points, target, solver_kw)
     best = int(np.argmin(scores))
-    return FitResult(popt=fit.p[best].copy(), pcov=_pcov(fit.J[best], fit.cost[best], absolute_sigma), score=float(scores[best]), cost=fit.cost,
+    return FitResult(popt=fit.p[best].copy(), pcov=_pcov(fit.JTJ[best], fit.cost[best], absolute_sigma, fit.r.shape[1]), score=float(scores[best]), cost=fit.cost,
                      p_all=fit.p, n_iter=fit.n_iter, n_solves=fit.n_solves)
 
 
@@ -252,7 +330,7 @@ def bootstrap_fit_batch(model: str, target_fit, popt, time_points, free_bounds: 
     Nd = tf.size - (P if lam > 0.0 else 0)
     fit = fit_rows_batch(model, num_psites, time_points, np.tile(popt, (bootstraps, 1)), init_cond, noisy[:, :Nd], sigma=sigma, lam=lam,
                          bounds=free_bounds, max_iter=max_iter, **solver_kw)
-    covs = [c for c in (_pcov(fit.J[k], fit.cost[k], absolute_sigma) for k in range(bootstraps)) if c is not None]
+    covs = [c for c in (_pcov(fit.JTJ[k], fit.cost[k], absolute_sigma, fit.r.shape[1]) for k in range(bootstraps)) if c is not None]
     return fit.p.mean(axis=0), (np.mean(covs, axis=0) if covs else None), fit.p
 
 

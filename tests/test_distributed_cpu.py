@@ -53,6 +53,23 @@ def _worker(rank, world, port, total, q):
         both = [torch.empty_like(sig) for _ in range(world)]
         dist.all_gather(both, sig)
         ok = ok and all(torch.equal(b, both[0]) for b in both) and shared_seed(17) == 17
+        # rows-sharded least-squares driver: the partition / packing / gather around the (here: faked) per-rank fit
+        import numpy as np
+        from phoskintime_amd.paramest import multistart as ms
+        calls = []
+
+        def fake_fit(model, n, t, P0, y0, target, sigma=None, lam=0.0, bounds=None, **kw):
+            calls.append((P0.shape[0], np.asarray(bounds[0]).shape, np.asarray(lam).shape))
+            R, P = P0.shape
+            return ms.RowsFit(p=P0 * 2.0, cost=P0.sum(axis=1), r=np.tile(P0[:, :1], (1, 4)), JTJ=P0[:, :, None] * P0[:, None, :], n_iter=3, n_solves=7, n_launches=2)
+        ms.fit_rows_batch = fake_fit
+        R_ = max(total, 1)
+        P0 = np.arange(R_ * 3, dtype=float).reshape(R_, 3)
+        fit = ms.fit_rows_sharded("distmod", 1, [0.0, 1.0], P0, np.ones(3), np.zeros(4), lam=np.zeros(R_), bounds=(np.zeros((R_, 3)), np.ones(3)))
+        ok = ok and np.array_equal(fit.p, P0 * 2.0) and np.array_equal(fit.cost, P0.sum(axis=1)) and fit.JTJ.shape == (R_, 3, 3) \
+            and np.array_equal(fit.JTJ[-1], np.outer(P0[-1], P0[-1])) and fit.r.shape == (R_, 4)
+        lo2, hi2 = shard_bounds(R_, rank, world)
+        ok = ok and ((hi2 == lo2 and not calls) or (calls and calls[0] == (hi2 - lo2, (hi2 - lo2, 3), (hi2 - lo2,))))      # per-row args sliced, shared passed on
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -81,3 +81,27 @@ def test_oracle_frechet_restatement_matches_reference():
     g = np.load(GOLD[0].parent / "frechet.npz")
     for k in range(g["dist"].size):
         assert abs(nm.frechet_distance(g[f"a{k}"], g[f"b{k}"]) - g["dist"][k]) <= 1e-12 * max(1.0, g["dist"][k])
+
+
+LARGE = sorted((Path(__file__).resolve().parent / "golden").glob("netlarge_m*.npz"))
+
+
+def test_large_network_inventory():
+    """One N = 100 / S ~ 550 network per topology at BASELINE config 4 / 5 size, run through the reference once (VERDICT r1 missing #4)."""
+    assert [f.name for f in LARGE] == [f"netlarge_m{m}.npz" for m in (0, 1, 2, 4)]
+    for f in LARGE:
+        g = np.load(f)
+        assert int(g["N"]) == 100 and 500 <= int(g["S"]) <= 600 and g["Y_lsoda8"].shape[0] == 2 and g["Y_tight"].shape[0] == 1
+
+
+@pytest.mark.parametrize("f", LARGE, ids=lambda f: f.stem)
+def test_large_network_rhs_bit_exact(f):
+    g = np.load(f); net = nm.Network.from_npz(g)
+    np.testing.assert_array_equal(nm.default_y0(net), g["y0"])
+    for k in range(2):
+        p = nm.Params.from_npz(g, k)
+        for ti, t in enumerate(g["t_probe"]):
+            np.testing.assert_array_equal(nm.rhs(net, p, g["y_rand"][k], t), g["rhs_rand"][k, ti])
+    # the reference's optimiser-tolerance run (1e-8) against its own 1e-12 run: the error the parity band has to live with
+    band = np.max(np.abs(g["Y_lsoda8"][0] - g["Y_tight"][0]) / (1e-8 + 1e-6 * np.abs(g["Y_tight"][0])))
+    assert band < 5.0
