@@ -256,6 +256,12 @@ def main():
             if pj.get("kernel") == kname:
                 res["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
                 res["roofline"]["traffic_source"] = "committed profile profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 correction); not re-measured in this run" % prof[-1].name
+                if "f64_flops_executed_per_launch" in pj:
+                    ex = pj["f64_flops_executed_per_launch"] / (kernel_ms * 1e-3) / 1e12
+                    res["roofline_fp64"].update({"executed_flops_per_launch": pj["f64_flops_executed_per_launch"], "executed_tflops": ex,
+                                                 "executed_frac_of_spec_peak": ex / FP64_VALU_PEAK_TFLOPS,
+                                                 "f64_share_of_valu_insts": (pj["SQ_INSTS_VALU_FMA_F64"] + pj["SQ_INSTS_VALU_ADD_F64"] + pj["SQ_INSTS_VALU_MUL_F64"] + pj["SQ_INSTS_VALU_TRANS_F64"]) / pj["SQ_INSTS_VALU"],
+                                                 "executed_source": "SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of the committed profile profiles/%s x 64 lanes (FMA = 2), kernel time from this run" % prof[-1].name})
                 res["valu_issue"] = {"valu_insts_per_launch": pj["SQ_INSTS_VALU"], "lds_insts_per_launch": pj["SQ_INSTS_LDS"],
                                      "busy_frac_at_4clk_2p1GHz": pj["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.1e9 * kernel_ms * 1e-3),
                                      "note": "instruction counts from the committed profile %s, kernel time from this run; 1024 SIMDs, ~2.1 GHz under FP64 load" % prof[-1].name}

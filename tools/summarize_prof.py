@@ -9,7 +9,7 @@ def rows(pattern):
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for r in rows("stats/**/*kernel_stats.csv"):
     print("  %-90s calls %5s  avg %12.1f ns  total %14s ns  %6s %%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]), r["TotalDurationNs"], r["Percentage"]))
-for name, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv"), ("SQ", "pmc_sq/**/*counter_collection.csv")):
+for name, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv"), ("SQ", "pmc_sq/**/*counter_collection.csv"), ("F64 mix", "pmc_f64/**/*counter_collection.csv")):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows(pat):
         acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
