@@ -82,7 +82,17 @@ typedef struct pk_solver_opts {
   int32_t kernel;       /* PK_KERNEL_*: which kernel family runs a small system.  AUTO picks by batch size (thread-per-replica above a
                            measured threshold), so the SAME replica can take different roundings / step sequences in batches of
                            different size -- a sharded run that must reproduce the single-GPU bits pins GROUP or TPR on every rank. */
+  int32_t err_norm;     /* PK_NORM_*: how the local error of a step is measured against rtol / atol (pk_network_simulate_batch; the per-protein
+                           kernels always use the max norm)                                                                          */
 } pk_solver_opts;
+
+enum {
+  PK_NORM_DEFAULT = 0,  /* = PK_NORM_MAX                                                                                              */
+  PK_NORM_MAX     = 1,  /* max_i |e_i| / (atol + rtol |y_i|): every component inside its tolerance (1.4-1.7x the steps of RMS at S ~ 550)   */
+  PK_NORM_RMS     = 2   /* sqrt(mean_i (e_i / (atol + rtol |y_i|))^2): ODEPACK's vnorm, i.e. what the reference's LSODA controls with the
+                           same rtol / atol (scipy.integrate.odeint, global_model/simulate.py:69-79).  Opt-in: 1.4-1.7x fewer steps, accuracy
+                           of the reference run's own class on the fixtures but outside the parity band on some populations   */
+};
 
 enum {
   PK_KERNEL_AUTO  = 0,  /* by batch size (default)                                                             */

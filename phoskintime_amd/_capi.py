@@ -21,6 +21,7 @@ LINSOLVE_AUTO, LINSOLVE_DENSE, LINSOLVE_STRUCTURED = 0, 1, 2
 LINSOLVES = {"auto": LINSOLVE_AUTO, "dense": LINSOLVE_DENSE, "structured": LINSOLVE_STRUCTURED}
 KERNEL_AUTO, KERNEL_GROUP, KERNEL_TPR = 0, 1, 2
 KERNELS = {"auto": KERNEL_AUTO, "group": KERNEL_GROUP, "tpr": KERNEL_TPR}
+NORMS = {"default": 0, "max": 1, "rms": 2}
 METRICS = {"total_signal": 0, "mean_activity": 1, "variance": 2, "dynamics": 3, "l2_norm": 4}
 ST_NONFINITE, ST_MAXSTEPS, ST_HMIN = 1, 2, 4
 
@@ -55,7 +56,7 @@ class SolverOpts(C.Structure):
     """Mirror of ``pk_solver_opts`` (include/phoskin.h)."""
     _fields_ = [("method", C.c_int32), ("linsolve", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double),
                 ("h0", C.c_double), ("rk4_h", C.c_double), ("max_steps", C.c_int32), ("clip_nonneg", C.c_int32),
-                ("normalize", C.c_int32), ("stage_form", C.c_int32), ("kernel", C.c_int32)]
+                ("normalize", C.c_int32), ("stage_form", C.c_int32), ("kernel", C.c_int32), ("err_norm", C.c_int32)]
 
 
 #: every symbol include/phoskin.h declares (tests/test_capi_symbols.py checks the header against this list)
@@ -152,6 +153,8 @@ def default_opts(**kw) -> SolverOpts:
             v = LINSOLVES[v]
         if k == "kernel" and isinstance(v, str):
             v = KERNELS[v]
+        if k == "err_norm" and isinstance(v, str):
+            v = NORMS[v]
         if not hasattr(o, k):
             raise TypeError(f"unknown solver option {k!r}")
         setattr(o, k, v)

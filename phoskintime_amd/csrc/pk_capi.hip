@@ -104,6 +104,7 @@ void pk_default_opts(pk_solver_opts* o) {
   o->clip_nonneg = 1;
   o->normalize = 0;
   o->kernel = PK_KERNEL_AUTO;
+  o->err_norm = PK_NORM_DEFAULT;
 }
 
 int pk_protein_n_states(int model, int n_sites) {

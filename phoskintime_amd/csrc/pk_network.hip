@@ -252,6 +252,8 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.x_is_raw = x_is_raw; a.y0 = y0; a.y0_batched = y0_is_batched ? 1 : 0; a.t0 = t_host[0]; a.T = T; a.Y = Y;
   a.status = status; a.n_steps = n_steps; a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.max_steps = o.max_steps;
+  if (o.err_norm < PK_NORM_DEFAULT || o.err_norm > PK_NORM_RMS) return pk_ctx_fail(c, PK_ERR_ARG, "unknown opts->err_norm");
+  a.err_rms = (o.err_norm == PK_NORM_RMS) ? 1 : 0;
   a.n_stops = (int)st.size();
   if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
   hipStream_t stream = (hipStream_t)pk_ctx_stream(c);

@@ -43,6 +43,7 @@ struct NetSolveArgs {
   double* Y;                       // [B, T, S]
   int32_t* status; int32_t* n_steps;
   double rtol, atol, h0; int max_steps;
+  int err_rms;                     // 1: ODEPACK's weighted root-mean-square error norm (what the reference's LSODA controls); 0: max norm
 };
 
 // block-wide NaN-propagating max; `red` holds >= 17 doubles of LDS
@@ -56,6 +57,25 @@ __device__ __forceinline__ double block_max(double v, double* red) {
   double r = red[0];
   for (int i = 1; i < nw; ++i) r = mx(r, red[i]);
   return r;
+}
+
+// block-wide sum (NaN / inf propagate by themselves); `red` holds >= 17 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+// local error of a step from the per-thread partial value `e`: max over all states, or sqrt(mean of squares) (ODEPACK vnorm)
+__device__ __forceinline__ double err_reduce(double e, const bool rms, const int S, double* red) {
+  return rms ? sqrt(block_sum(e, red) / S) : block_max(e, red);
+}
+__device__ __forceinline__ double err_acc(double a, double q, const bool rms) {
+  return rms ? __builtin_fma(q, q, a) : ((q > a || q != q) ? q : a);
 }
 
 template <int MODEL>
@@ -290,10 +310,10 @@ __global__ __launch_bounds__(256, 3) void net_solve_kernel(const NetDev n, const
         const double yn = Ys[k] + U4[k];
         const double ev = E1 * U1[k] + E2 * U2[k] + E3 * U3[k] + E4 * U4[k];
         const double q = fabs(ev) / (A.atol + A.rtol * fmax(fabs(y[k]), fabs(yn)));
-        e = (q > e || q != q) ? q : e;
+        e = err_acc(e, q, A.err_rms);
         R_[k] = yn;
       }
-      const double err = block_max(e, red);
+      const double err = err_reduce(e, A.err_rms, S, red);
       if (err != err || err > 1e300) {
         ++nrej; after_reject = true; h = 0.1 * hs;
         double bad = 0.0;

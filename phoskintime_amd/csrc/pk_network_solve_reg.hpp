@@ -229,16 +229,17 @@ __global__ __launch_bounds__(256, 2) void net_solve_reg_kernel(const NetDev n, c
       double nS[MAXS];
       auto q = [&](double ev, double ya, double yb) { return fabs(ev) * net_rcp(A.atol + A.rtol * fmax(fabs(ya), fabs(yb))); };
       auto mx = [](double a, double c) { return (a > c || a != a) ? a : c; };
+      const bool rms = A.err_rms;
       double e = 0.0;
       if (own) {
-        e = mx(q(E1 * UR[0] + E2 * UR[1] + E3 * UR[2] + E4 * UR[3], yR, nR), q(E1 * UP[0] + E2 * UP[1] + E3 * UP[2] + E4 * UP[3], yP, nP));
+        e = err_acc(err_acc(0.0, q(E1 * UR[0] + E2 * UR[1] + E3 * UR[2] + E4 * UR[3], yR, nR), rms), q(E1 * UP[0] + E2 * UP[1] + E3 * UP[2] + E4 * UP[3], yP, nP), rms);
       }
 #pragma unroll
       for (int j = 0; j < MAXS; ++j) {
         nS[j] = Ysv[j] + Us[3][j];
-        if (j < ns) e = mx(e, q(E1 * Us[0][j] + E2 * Us[1][j] + E3 * Us[2][j] + E4 * Us[3][j], ys[j], nS[j]));
+        if (j < ns) e = err_acc(e, q(E1 * Us[0][j] + E2 * Us[1][j] + E3 * Us[2][j] + E4 * Us[3][j], ys[j], nS[j]), rms);
       }
-      const double err = block_max(e, red);
+      const double err = err_reduce(e, rms, S, red);
       if (err != err || err > 1e300) {
         ++nrej; after_reject = true; h = 0.1 * hs;
         double bad = (nonfinite(yR) || nonfinite(yP) || nonfinite(Ai) || nonfinite(Bi) || nonfinite(Ci) || nonfinite(Di) || nonfinite(Ei) ||

@@ -188,13 +188,14 @@ __global__ __launch_bounds__(256, 2) void net_solve_reg2_kernel(const NetDev n, 
       double nM[NM];
       auto q = [&](double ev, double ya, double yb) { return fabs(ev) * net_rcp(A.atol + A.rtol * fmax(fabs(ya), fabs(yb))); };
       auto mx = [](double a, double c) { return (a > c || a != a) ? a : c; };
-      double e = own ? q(E1 * UR[0] + E2 * UR[1] + E3 * UR[2] + E4 * UR[3], yR, nR) : 0.0;
+      const bool rms = A.err_rms;
+      double e = own ? err_acc(0.0, q(E1 * UR[0] + E2 * UR[1] + E3 * UR[2] + E4 * UR[3], yR, nR), rms) : 0.0;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         nM[m] = Ym[m] + Um[3][m];
-        if (own && m < nst) e = mx(e, q(E1 * Um[0][m] + E2 * Um[1][m] + E3 * Um[2][m] + E4 * Um[3][m], ym[m], nM[m]));
+        if (own && m < nst) e = err_acc(e, q(E1 * Um[0][m] + E2 * Um[1][m] + E3 * Um[2][m] + E4 * Um[3][m], ym[m], nM[m]), rms);
       }
-      const double err = block_max(e, red);
+      const double err = err_reduce(e, rms, S, red);
       if (err != err || err > 1e300) {
         ++nrej; after_reject = true; h = 0.1 * hs;
         double bad = (nonfinite(yR) || nonfinite(Ai) || nonfinite(Bi) || nonfinite(Ci) || nonfinite(Di) || nonfinite(Ei) || nonfinite(ts)) ? 1.0 : 0.0;
