@@ -43,8 +43,13 @@ enum {
                            1 factorisation per step, order 7 with an embedded order-6 estimate */
   PK_METHOD_LRP12  = 5, /* the same construction with 12 solves: order 11, embedded order 10, gamma = 0.16 (L-stable; |R(iy)| <= 1 + 4.5e-9);
                            about half the steps of LRP8 at equal accuracy.  Default. */
-  PK_METHOD_DP5    = 4  /* pk_network_simulate_batch only: the reference's opt-in explicit integrator, step for step -- Dormand-Prince
+  PK_METHOD_DP5    = 4, /* pk_network_simulate_batch only: the reference's opt-in explicit integrator, step for step -- Dormand-Prince
                            5(4), PI controller, dt in [1e-6, 1], bucket-edge landing, Hermite output (global_model/solvers.py:293-758) */
+  PK_METHOD_ARK436 = 6, /* pk_network_simulate_batch only: ARK4(3)6L[2]SA (Kennedy-Carpenter) as a linearly implicit additive method, implicit
+                           on the per-protein block Jacobian: order 4 for any Jacobian approximation, 5 block solves per step.  The network
+                           default wherever the one-thread-per-protein layout applies (topologies 0 / 1 / 4, <= 8 sites, N <= 256)          */
+  PK_METHOD_ROS34PW2 = 7 /* pk_network_simulate_batch only: the round-1 integrator, Rosenbrock-W of order 3 (4 block solves per step); every
+                           network / topology; the default where ARK436 does not apply                                                       */
 };
 
 /* Linear solver for the implicit stage equations (g I - J) x = r. */
@@ -216,9 +221,10 @@ int pk_network_jacobian_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int 
                               const double* t, int t_is_batched, double* J);
 /* Replaces global_model.simulate.simulate_odeint(sys, t_eval, rtol, atol, mxstep) -> Y[T,S] (simulate.py:34-80) for B candidates
  * of one network: x [B,n_var] and y0 ([S] or [B,S]) are device pointers, t is a HOST pointer to T strictly increasing times
- * (t[0] = initial time), Y [B,T,S] device.  Integrator: ROS34PW2 Rosenbrock-W with the per-protein diagonal blocks of the analytic
- * Jacobian for every opts->method except PK_METHOD_DP5, which selects the reference's explicit RK45 (jacspeedup.solve_custom,
- * jacspeedup.py:31-64; h0 = dt_init, 0 -> 0.05; max_steps <= 0 -> 2 000 000).  opts->rtol / atol / h0 / max_steps are honoured.
+ * (t[0] = initial time), Y [B,T,S] device.  Integrator: linearly implicit with the per-protein diagonal blocks of the analytic Jacobian
+ * (DESIGN.md): PK_METHOD_ARK436 (order 4) where its kernel applies, else PK_METHOD_ROS34PW2 (order 3); either can be requested by name,
+ * every other opts->method value means "the default"; PK_METHOD_DP5 selects the reference's explicit RK45 (jacspeedup.solve_custom,
+ * jacspeedup.py:31-64; h0 = dt_init, 0 -> 0.05; max_steps <= 0 -> 2 000 000).  opts->rtol / atol / h0 / max_steps / err_norm are honoured.
  * All four topologies; combinatorial blocks (2) up to 3 sites per protein run out of registers, larger ones (<= 16 sites) in the LDS kernel. */
 int pk_network_simulate_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
                               const double* t_host, int T, const pk_solver_opts* opts, double* Y, int32_t* status, int32_t* n_steps);

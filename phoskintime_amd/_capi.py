@@ -15,8 +15,8 @@ LIB_PATH = _HERE / "libphoskin_hip.so"
 DIST, SUCC, RAND = 0, 1, 2
 MODEL_IDS = {"distmod": DIST, "succmod": SUCC, "randmod": RAND}
 MODEL_NAMES = {v: k for k, v in MODEL_IDS.items()}
-METHOD_RODAS4, METHOD_BDF2, METHOD_RK4, METHOD_LRP8, METHOD_DP5, METHOD_LRP12 = 0, 1, 2, 3, 4, 5
-METHODS = {"rodas4": METHOD_RODAS4, "bdf2": METHOD_BDF2, "rk4": METHOD_RK4, "lrp8": METHOD_LRP8, "dp5": METHOD_DP5, "lrp12": METHOD_LRP12}
+METHOD_RODAS4, METHOD_BDF2, METHOD_RK4, METHOD_LRP8, METHOD_DP5, METHOD_LRP12, METHOD_ARK436, METHOD_ROS34PW2 = 0, 1, 2, 3, 4, 5, 6, 7
+METHODS = {"rodas4": METHOD_RODAS4, "bdf2": METHOD_BDF2, "rk4": METHOD_RK4, "lrp8": METHOD_LRP8, "dp5": METHOD_DP5, "lrp12": METHOD_LRP12, "ark436": METHOD_ARK436, "ros34pw2": METHOD_ROS34PW2}
 LINSOLVE_AUTO, LINSOLVE_DENSE, LINSOLVE_STRUCTURED = 0, 1, 2
 LINSOLVES = {"auto": LINSOLVE_AUTO, "dense": LINSOLVE_DENSE, "structured": LINSOLVE_STRUCTURED}
 KERNEL_AUTO, KERNEL_GROUP, KERNEL_TPR = 0, 1, 2

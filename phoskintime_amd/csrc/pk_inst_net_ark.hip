@@ -1,0 +1,39 @@
+// Instantiations + launcher of the order-4 network integrator (pk_network_solve_ark.hpp): topologies 0 / 1 / 4, site classes 4 / 6 / 8.
+#include "pk_network_solve_ark.hpp"
+#include <atomic>
+
+namespace pk {
+
+static int site_class(int max_sites) { return max_sites <= 4 ? 4 : max_sites <= 6 ? 6 : 8; }
+
+size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads) { return net_solve_ark_lds_bytes(n, nnzT, 2 + site_class(max_sites), threads); }
+
+template <int M, int MS>
+static hipError_t launch_one(const NetDev& n, const NetSolveArgs& a, long long B, int threads, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {                                  // beyond the default dynamic-LDS limit: raise it per (kernel, device)
+    static std::atomic<uint64_t> ready{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev < 64 ? (1ull << dev) : 0;
+    if (!bit || !(ready.load(std::memory_order_acquire) & bit)) {
+      e = hipFuncSetAttribute((const void*)net_solve_ark_kernel<M, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      ready.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL((net_solve_ark_kernel<M, MS>), dim3((unsigned)B), dim3(threads), lds, st, n, a);
+  return hipSuccess;
+}
+
+hipError_t launch_net_ark(const NetDev& n, const NetSolveArgs& a, int max_sites, long long B, int threads, size_t lds, hipStream_t st) {
+  const int cls = site_class(max_sites);
+#define PK_ARK(M)                                                                   \
+  (cls == 4 ? launch_one<M, 4>(n, a, B, threads, lds, st) : cls == 6 ? launch_one<M, 6>(n, a, B, threads, lds, st) : launch_one<M, 8>(n, a, B, threads, lds, st))
+  if (n.model == 0) return PK_ARK(0);
+  if (n.model == 1) return PK_ARK(1);
+  return PK_ARK(4);
+#undef PK_ARK
+}
+
+}  // namespace pk

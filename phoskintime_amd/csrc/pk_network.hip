@@ -9,6 +9,11 @@
 #include "pk_network_solve_reg.hpp"
 #include "pk_network_solve_reg2.hpp"
 #include "pk_network_rk45.hpp"
+namespace pk {
+// order-4 additive integrator (pk_network_solve_ark.hpp), its own translation unit: returns the dynamic LDS it needs, or launches
+size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads);
+hipError_t launch_net_ark(const NetDev& n, const NetSolveArgs& a, int max_sites, long long B, int threads, size_t lds, hipStream_t st);
+}
 #include <algorithm>
 #include <cstdlib>
 
@@ -89,6 +94,7 @@ struct pk_net {
   size_t solve_lds_bytes;
   size_t solve_reg_lds_bytes;
   int max_sites;
+  int nnzT = 0;
   std::vector<double> kin_grid_host;
   double* stops_dev = nullptr; int32_t* stop_out_dev = nullptr; size_t stops_cap = 0;
 };
@@ -149,6 +155,7 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
   n->lds_bytes = ((size_t)v.n_var + v.S + v.n_K + v.sites + 3 * (size_t)v.N) * sizeof(double);
   n->solve_lds_bytes = pk::net_solve_lds_bytes(v, nnzT);
   n->solve_reg_lds_bytes = pk::net_solve_reg_lds_bytes(v, nnzT);
+  n->nnzT = nnzT;
   n->max_sites = 0;
   for (int i = 0; i < d->N; ++i) n->max_sites = std::max(n->max_sites, (int)d->n_sites[i]);
   n->kin_grid_host.assign(d->kin_grid, d->kin_grid + d->n_grid);
@@ -297,6 +304,20 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
     else                   hipLaunchKernelGGL((pk::net_solve_reg2_kernel<3>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
     hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e2));
+  }
+  // ---- default integrator: ARK436 (order 4) in the one-thread-per-protein layout; ROS34PW2 (order 3) everywhere else / on request
+  {
+    const int threads_a = ((n->d.N + 63) / 64) * 64;
+    const bool ark_fits = n->d.model != 2 && n->d.N <= 256 && n->max_sites <= 8 && o.linsolve != PK_LINSOLVE_STRUCTURED;
+    const size_t lds_a = ark_fits ? pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) : 0;
+    const bool ark_ok = ark_fits && lds_a <= 160 * 1024;
+    if (o.method == PK_METHOD_ARK436 && !ark_ok)
+      return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "PK_METHOD_ARK436: topologies 0 / 1 / 4 with <= 8 sites per protein and N <= 256 (use PK_METHOD_ROS34PW2)");
+    if (ark_ok && o.method != PK_METHOD_ROS34PW2) {
+      hipError_t ea = pk::launch_net_ark(n->d, a, n->max_sites, (long long)B, threads_a, lds_a, stream);
+      if (ea == hipSuccess) ea = hipGetLastError();
+      return ea == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(ea));
+    }
   }
   const bool reg_ok = n->d.model != 2 && n->d.N <= 256 && n->max_sites <= 8 && n->solve_reg_lds_bytes <= 64 * 1024 && o.linsolve != PK_LINSOLVE_STRUCTURED;
   if (reg_ok) {

@@ -135,18 +135,25 @@ class NetworkEngine:
         out._keepalive = (xd, yd, td)  # type: ignore[attr-defined]
         return out
 
-    def simulate_batch(self, x, t_eval, y0=None, raw: bool = False, rtol: float = 1e-7, atol: float = 1e-9, max_steps: int = 1000000,
-                       h0: float = 0.0, kernel: str = "auto", method: str = "rosw", err_norm: str = "max"):
+    def simulate_batch(self, x, t_eval, y0=None, raw: bool = False, rtol: Optional[float] = None, atol: Optional[float] = None, max_steps: int = 1000000,
+                       h0: float = 0.0, kernel: str = "auto", method: str = "auto", err_norm: str = "max"):
         """Y [B, T, S] for B candidates: reference ``simulate_odeint(sys, t_eval, rtol, atol, mxstep)`` (simulate.py:34-80) batched.
         Returns (Y, status [B], n_steps [B, 2]) as GPU tensors; flagged candidates have NaN rows (callers test np.isfinite,
-        optproblem.py:125-133).  method = "rosw": the Rosenbrock-W production integrator; "dp5": the reference's explicit RK45
-        (solvers.py:293-758) step for step.  err_norm = "max" (default: every component inside its tolerance) or "rms" (ODEPACK's weighted
+        optproblem.py:125-133).  method = "auto": the order-4 additive method ARK436 where its kernel applies (topologies 0 / 1 / 4, <= 8
+        sites per protein, N <= 256), else the order-3 Rosenbrock-W method; "ark" / "rosw" request one of them; "dp5": the reference's
+        explicit RK45 (solvers.py:293-758) step for step.  err_norm = "max" (default: every component inside its tolerance) or "rms" (ODEPACK's weighted
         root-mean-square norm, i.e. what the reference's LSODA controls with the same rtol / atol: 1.4-1.7x fewer steps).  Measured
         (tools/gpu_norm_scan.py): on the reference-run fixtures the RMS run at 1e-8 / 1e-8 lands 0.04-0.27 band widths from LSODA at 1e-12
         (the reference's own LSODA run at those settings: 0.05-0.43), but on random full-size combinatorial populations it reaches 2 band
         widths and at 1e-5 / 1e-7 it is 6x less accurate than LSODA -- the order-3 method's error constant is larger.  Hence opt-in."""
-        if method not in ("rosw", "dp5"):
-            raise ValueError("method must be 'rosw' or 'dp5'")
+        if rtol is None or atol is None:
+            # parity-grade defaults (worst band error over every reference-run fixture <= 0.3, tools/gpu_norm_scan.py): the order-4 method
+            # at the reference optimiser's own tolerances (config.toml:403-404), the order-3 method at 1e-7 / 1e-9
+            ark = self.ark_eligible() and method in ("auto", "ark") and kernel != "lds"
+            rtol = (1e-8 if ark else 1e-7) if rtol is None else rtol
+            atol = (1e-8 if ark else 1e-9) if atol is None else atol
+        if method not in ("auto", "ark", "rosw", "dp5"):
+            raise ValueError("method must be 'auto', 'ark', 'rosw' or 'dp5'")
         dev = torch.device("cuda", self.ctx.device)
         xd = _dev_f64(x, dev)
         if xd.dim() == 1:
@@ -168,12 +175,17 @@ class NetworkEngine:
         nsteps = torch.zeros((B, 2), dtype=torch.int32, device=dev)
         # kernel = "auto": register-resident one-thread-per-protein kernel when eligible; "lds": the general LDS kernel
         opts = _capi.default_opts(rtol=rtol, atol=atol, max_steps=max_steps, h0=h0, linsolve=("structured" if kernel == "lds" else "auto"),
-                                  method=("dp5" if method == "dp5" else None), err_norm=err_norm)
+                                  method={"dp5": "dp5", "ark": "ark436", "rosw": "ros34pw2"}.get(method), err_norm=err_norm)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         self.ctx.check(self.ctx.lib.pk_network_simulate_batch(self.ctx.handle, self._h, B, _ptr(xd), int(raw), _ptr(yd), yb, th.ctypes.data, T,
                                                              C.byref(opts), _ptr(Y), _ptr(status), _ptr(nsteps)))
         Y._keepalive = (xd, yd)  # type: ignore[attr-defined]
         return Y, status, nsteps
+
+    def ark_eligible(self) -> bool:
+        """Whether pk_network_simulate_batch runs the order-4 additive integrator on this network (one thread per protein: topologies
+        0 / 1 / 4, at most 8 sites per protein, N <= 256)."""
+        return self.model != 2 and self.N <= 256 and (int(self._keep[2].max()) if self.N else 0) <= 8
 
     # ------------------------------------------------------------------ loss / objectives
     def make_loss(self, loss_data: dict, T: int):

@@ -76,10 +76,14 @@ def scalar_metric_batch(pred: torch.Tensor, metric: str = "total_signal") -> tor
 def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, times_r, times_ph, perturbation: float = config.SENSITIVITY_PERTURBATION,
                           trajectories: int = config.SENSITIVITY_TRAJECTORIES, num_levels: int = config.SENSITIVITY_LEVELS,
                           metric: str = config.SENSITIVITY_METRIC, seed: Optional[int] = None,
-                          param_values: Optional[np.ndarray] = None, y0=None, conf_level: float = 0.95, rtol: float = 1e-5, atol: float = 1e-7):
+                          param_values: Optional[np.ndarray] = None, y0=None, conf_level: float = 0.95, rtol: Optional[float] = None, atol: Optional[float] = None):
     """Returns dict(Si, problem, param_values, Y, status).  ``fitted_params`` maps the eight parameter groups (System.update order)
     to arrays / a scalar; every entry is varied, as in the reference (sensitivity.py:196-215)."""
     params = {k: (np.asarray(fitted_params[k], float) if k != "tf_scale" else float(fitted_params[k])) for k in _ORDER}
+    from .simulate import measure_tolerances                  # the settings of simulate_and_measure, which the reference's workers call
+    tol = measure_tolerances(eng)
+    rtol = tol["rtol"] if rtol is None else rtol
+    atol = tol["atol"] if atol is None else atol
     problem = compute_bounds(params, perturbation)
     design = None
     seed = shared_seed(seed)              # N > 1 ranks: every rank must build the SAME design (seed=None would give each its own)
