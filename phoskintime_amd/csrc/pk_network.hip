@@ -314,7 +314,15 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
     if (o.method == PK_METHOD_ARK436 && !ark_ok)
       return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "PK_METHOD_ARK436: topologies 0 / 1 / 4 with <= 8 sites per protein and N <= 256 (use PK_METHOD_ROS34PW2)");
     if (ark_ok && o.method != PK_METHOD_ROS34PW2) {
-      hipError_t ea = pk::launch_net_ark(n->d, a, n->max_sites, (long long)B, threads_a, lds_a, stream);
+      // The order-4 method runs at 0.5 x the requested tolerances.  Measured on BASELINE config 5's population (8 192 candidates of the
+      // reference-built N = 100 network, rtol = atol = 1e-8): factor 1 -> 914 steps, 0.085 band widths from LSODA@1e-12 on the fixture
+      // candidate, up to 0.82 between the two integrators over the population; 0.5 -> 1 102 steps, 0.048 (the reference's own LSODA run at
+      // these tolerances: 0.054), 0.34; 0.25 -> 1 329 steps, 0.023, 0.20.  0.5 lands on the reference run's accuracy with a 3x margin
+      // inside the parity band over the population (dev knob: PK_ARK_TOLFAC, read once)
+      static const double tolfac = [] { const char* v = getenv("PK_ARK_TOLFAC"); const double f = v ? atof(v) : 0.0; return (f > 0.0 && f <= 1.0) ? f : 0.5; }();
+      pk::NetSolveArgs aa = a;
+      aa.rtol *= tolfac; aa.atol *= tolfac;
+      hipError_t ea = pk::launch_net_ark(n->d, aa, n->max_sites, (long long)B, threads_a, lds_a, stream);
       if (ea == hipSuccess) ea = hipGetLastError();
       return ea == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(ea));
     }

@@ -61,3 +61,51 @@ if __name__ == '__main__':
                 Yr, nr, rr = rw.solve(net, p, g['y0'], g['t_eval'], rtol, atol, False)
                 print('%-22s set %d %.0e/%.0e: ARK436 %5d steps (%d rej, %d stage solves) band %.4f | ROS34PW2 %5d steps (%d stage solves) band %.4f | ref lsoda8 %.3f' % (
                     fn.split('/')[-1], k, rtol, atol, na, ra, 5*na, rw.band(Ya, g['Y_tight'][k]), nr, 4*nr, rw.band(Yr, g['Y_tight'][k]), rw.band(g['Y_lsoda8'][k], g['Y_tight'][k])), flush=True)
+
+
+def solve_sgs(net, p, y0, t_eval, rtol, atol):
+    """The same method with the combinatorial kernels' APPROXIMATE block factorisation P = (D_g - F) D_g^-1 (D_g - K) in place of g I - A:
+    the implicit operator becomes A~ = g I - P = A - F D_g^-1 K (it changes with the step size, which an additive method does not mind);
+    the defect F D_g^-1 K is then integrated by the EXPLICIT tableau -- this experiment asks whether its stability limit bites."""
+    mask = rw.block_mask(net)
+    stops = np.unique(np.concatenate([t_eval[1:], net.kin_grid[(net.kin_grid > t_eval[0]) & (net.kin_grid < t_eval[-1])]]))
+    y = y0.copy(); out = np.empty((len(t_eval), net.S)); out[0] = y
+    tc = t_eval[0]; I = np.eye(net.S); nst = nrej = 0
+    f = lambda yy, tt: nm.rhs(net, p, yy, tt)
+    h = 1e-3
+    for te in stops:
+        while True:
+            last = tc + 1.0001*h >= te
+            hs = te - tc if last else (0.5*(te-tc) if tc + 2*h > te else h)
+            tb = tc
+            Ab = rw.jac_cd(net, p, y, tb) * mask
+            g = 1.0/(hs*GAM)
+            D = np.diag(np.diag(Ab)); F = np.tril(Ab, -1); K = np.triu(Ab, 1)
+            Dg = g*I - D
+            P = (Dg - F) @ np.linalg.inv(Dg) @ (Dg - K)
+            At = g*I - P
+            Pinv = np.linalg.inv(P)
+            Fs = []; Gs = []
+            Y = y.copy(); Fs.append(f(Y, tb)); Gs.append(At @ Y)
+            for i in range(1, 6):
+                r = y + hs*sum(AEf[i, j]*(Fs[j] - Gs[j]) + AIf[i, j]*Gs[j] for j in range(i))
+                Y = Pinv @ (g*r)
+                Fs.append(f(Y, tb)); Gs.append(At @ Y)
+            yn = y + hs*sum(bf[j]*Fs[j] for j in range(6))
+            e = hs*sum((bf[j] - bhf[j])*Fs[j] for j in range(6))
+            err = np.max(np.abs(e)/(atol + rtol*np.maximum(np.abs(y), np.abs(yn))))
+            fac = max(1/6, min(5, err**(1/4)/0.9)); hnew = hs/fac; nst += 1
+            if err <= 1:
+                y = yn; tc += hs
+                if last:
+                    tc = te; h = max(hnew, h) if hs < h else hnew; break
+                h = hnew
+            else:
+                nrej += 1; h = hnew
+        idx = np.where(t_eval == te)[0]
+        if idx.size: out[idx[0]] = y
+    return out, nst, nrej
+
+
+if __name__ == '__main__' and False:
+    pass
