@@ -47,7 +47,8 @@ enum {
                            5(4), PI controller, dt in [1e-6, 1], bucket-edge landing, Hermite output (global_model/solvers.py:293-758) */
   PK_METHOD_ARK436 = 6, /* pk_network_simulate_batch only: ARK4(3)6L[2]SA (Kennedy-Carpenter) as a linearly implicit additive method, implicit
                            on the per-protein block Jacobian: order 4 for any Jacobian approximation, 5 block solves per step.  The network
-                           default wherever the one-thread-per-protein layout applies (topologies 0 / 1 / 4, <= 8 sites, N <= 256)          */
+                           default wherever the one-thread-per-protein layout applies (topologies 0 / 1 / 4, <= 8 sites, N <= 256); on
+                           request also for the combinatorial topology (<= 3 sites), where the order-3 kernel is the faster one     */
   PK_METHOD_ROS34PW2 = 7 /* pk_network_simulate_batch only: the round-1 integrator, Rosenbrock-W of order 3 (4 block solves per step); every
                            network / topology; the default where ARK436 does not apply                                                       */
 };

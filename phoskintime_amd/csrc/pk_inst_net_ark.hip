@@ -6,7 +6,11 @@ namespace pk {
 
 static int site_class(int max_sites) { return max_sites <= 4 ? 4 : max_sites <= 6 ? 6 : 8; }
 
-size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads) { return net_solve_ark_lds_bytes(n, nnzT, 2 + site_class(max_sites), threads); }
+// rows of a block vector: 2 + site class (topologies 0 / 1 / 4), 1 + 2^NB with NB = 2 or 3 (combinatorial)
+size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads) {
+  const int rows = n.model == 2 ? 1 + (max_sites <= 2 ? 4 : 8) : 2 + site_class(max_sites);
+  return net_solve_ark_lds_bytes(n, nnzT, rows, threads);
+}
 
 template <int M, int MS>
 static hipError_t launch_one(const NetDev& n, const NetSolveArgs& a, long long B, int threads, size_t lds, hipStream_t st) {
@@ -26,7 +30,26 @@ static hipError_t launch_one(const NetDev& n, const NetSolveArgs& a, long long B
   return hipSuccess;
 }
 
+template <int NB>
+static hipError_t launch_comb(const NetDev& n, const NetSolveArgs& a, long long B, int threads, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    static std::atomic<uint64_t> ready{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev < 64 ? (1ull << dev) : 0;
+    if (!bit || !(ready.load(std::memory_order_acquire) & bit)) {
+      e = hipFuncSetAttribute((const void*)net_solve_ark2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      ready.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL((net_solve_ark2_kernel<NB>), dim3((unsigned)B), dim3(threads), lds, st, n, a);
+  return hipSuccess;
+}
+
 hipError_t launch_net_ark(const NetDev& n, const NetSolveArgs& a, int max_sites, long long B, int threads, size_t lds, hipStream_t st) {
+  if (n.model == 2) return max_sites <= 2 ? launch_comb<2>(n, a, B, threads, lds, st) : launch_comb<3>(n, a, B, threads, lds, st);
   const int cls = site_class(max_sites);
 #define PK_ARK(M)                                                                   \
   (cls == 4 ? launch_one<M, 4>(n, a, B, threads, lds, st) : cls == 6 ? launch_one<M, 6>(n, a, B, threads, lds, st) : launch_one<M, 8>(n, a, B, threads, lds, st))

@@ -298,22 +298,19 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   }
   // Register-resident kernel (one thread per protein) when every block fits its per-thread arrays; opts->linsolve ==
   // PK_LINSOLVE_STRUCTURED forces the LDS kernel (kept as the general fallback and as the A/B reference).
-  if (comb_reg && o.linsolve != PK_LINSOLVE_STRUCTURED) {
-    const int threads2 = ((n->d.N + 63) / 64) * 64;
-    if (n->max_sites <= 2) hipLaunchKernelGGL((pk::net_solve_reg2_kernel<2>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
-    else                   hipLaunchKernelGGL((pk::net_solve_reg2_kernel<3>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
-    hipError_t e2 = hipGetLastError();
-    return e2 == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e2));
-  }
   // ---- default integrator: ARK436 (order 4) in the one-thread-per-protein layout; ROS34PW2 (order 3) everywhere else / on request
   {
     const int threads_a = ((n->d.N + 63) / 64) * 64;
-    const bool ark_fits = n->d.model != 2 && n->d.N <= 256 && n->max_sites <= 8 && o.linsolve != PK_LINSOLVE_STRUCTURED;
+    const bool ark_fits = n->d.N <= 256 && n->max_sites <= (n->d.model == 2 ? 3 : 8) && o.linsolve != PK_LINSOLVE_STRUCTURED;
     const size_t lds_a = ark_fits ? pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) : 0;
     const bool ark_ok = ark_fits && lds_a <= 160 * 1024;
     if (o.method == PK_METHOD_ARK436 && !ark_ok)
-      return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "PK_METHOD_ARK436: topologies 0 / 1 / 4 with <= 8 sites per protein and N <= 256 (use PK_METHOD_ROS34PW2)");
-    if (ark_ok && o.method != PK_METHOD_ROS34PW2) {
+      return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "PK_METHOD_ARK436: N <= 256 and <= 8 sites per protein (combinatorial topology: <= 3); use PK_METHOD_ROS34PW2");
+    // combinatorial topology: the additive kernel exists (PK_METHOD_ARK436 on request) and takes 2.4-2.7x fewer steps, but its step costs
+    // 2.8x a Rosenbrock-W step there (nine rows per thread: spills, the extra product with P, LDS parking): 18.3 k vs 20.9 k candidates/s
+    // at 1e-8 on the S = 900 population -- so the order-3 kernel stays the default for topology 2
+    const bool ark_default = ark_ok && n->d.model != 2;
+    if ((ark_default && o.method != PK_METHOD_ROS34PW2) || (ark_ok && o.method == PK_METHOD_ARK436)) {
       // The order-4 method runs at 0.5 x the requested tolerances.  Measured on BASELINE config 5's population (8 192 candidates of the
       // reference-built N = 100 network, rtol = atol = 1e-8): factor 1 -> 914 steps, 0.085 band widths from LSODA@1e-12 on the fixture
       // candidate, up to 0.82 between the two integrators over the population; 0.5 -> 1 102 steps, 0.048 (the reference's own LSODA run at
@@ -326,6 +323,13 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
       if (ea == hipSuccess) ea = hipGetLastError();
       return ea == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(ea));
     }
+  }
+  if (comb_reg && o.linsolve != PK_LINSOLVE_STRUCTURED) {
+    const int threads2 = ((n->d.N + 63) / 64) * 64;
+    if (n->max_sites <= 2) hipLaunchKernelGGL((pk::net_solve_reg2_kernel<2>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
+    else                   hipLaunchKernelGGL((pk::net_solve_reg2_kernel<3>), dim3((unsigned)B), dim3(threads2), n->solve_reg_lds_bytes, stream, n->d, a);
+    hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e2));
   }
   const bool reg_ok = n->d.model != 2 && n->d.N <= 256 && n->max_sites <= 8 && n->solve_reg_lds_bytes <= 64 * 1024 && o.linsolve != PK_LINSOLVE_STRUCTURED;
   if (reg_ok) {

@@ -361,6 +361,271 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark_kernel(const NetDev n, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Combinatorial topology (model 2), one thread per protein, 1 + 2^ns states (ns <= NB): the same additive method.  The register kernel
+// of round 1 (pk_network_solve_reg2.hpp) never forms g I - A_block; it applies the approximate factorisation
+//   P = (D_g - F) D_g^-1 (D_g - K),   D_g = g I + diag(loss),  F = phosphorylation (+ the C R -> state 0 coupling), K = dephosphorylation.
+// An additive method accepts that as it stands: the implicit operator is simply A~ := g I - P (= A_block - F D_g^-1 K; it depends on the
+// step size, which the order conditions do not mind), stage solves are  P Y_i = g r_i  (the two sweeps),  A~ Y_i = g (Y_i - r_i) falls out
+// as before, and only stage 1 needs one product with P.  numpy model: tools/proto_ark_network.py solve_sgs.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void net_solve_ark2_kernel(const NetDev n, const NetSolveArgs A) {
+  using namespace ark436;
+  constexpr int NM = 1 << NB;
+  constexpr int NR = 1 + NM;                         // rows of a block vector: mRNA, then the 2^NB bit-pattern states
+  extern __shared__ __align__(16) double lds[];
+  const int N = n.N, S = n.S;
+  double* Kt = lds;
+  double* Pv = Kt + n.n_K;
+  double* red = Pv + 2 * N;
+  const int nnzT = n.TF_indptr[N];
+  double* tf_dat = red + 24;
+  int32_t* tf_idx = reinterpret_cast<int32_t*>(tf_dat + nnzT);
+  double* park = tf_dat + nnzT + (nnzT + 1) / 2;     // [kArkSlots][NR][nt]
+  const NetSlices sl(n.n_K, N, n.sites);
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int i = tid;
+  const bool own = i < N;
+  const double* stops = A.stops_p ? A.stops_p : A.stops_v;
+  const int32_t* stop_out = A.stop_out_p ? A.stop_out_p : A.stop_out_v;
+  const double* xb = A.x + b * n.n_var;
+  auto par = [&](int off) { const double v = xb[off]; return A.x_is_raw ? softplus(v) : v; };
+  for (int k = tid; k < nnzT; k += nt) { tf_dat[k] = n.TF_data[k]; tf_idx[k] = n.TF_indices[k]; }
+
+  const int st = own ? n.offset_y[i] : 0, ss = own ? n.offset_s[i] : 0, ns = own ? n.n_sites[i] : 0;
+  const int nst = 1 << ns;
+  const int tf0 = own ? n.TF_indptr[i] : 0, tf1 = own ? n.TF_indptr[i + 1] : 0;
+  const double tfdeg_inv = own ? 1.0 / n.tf_deg[i] : 1.0;
+  const double Ai = own ? par(sl.A + i) : 0.0, Bi = own ? par(sl.B + i) : 1.0, Ci = own ? par(sl.C + i) : 0.0, Di = own ? par(sl.D + i) : 1.0,
+               Ei = own ? par(sl.E + i) : 0.0, ts = par(sl.tf);
+  double Dp[NB], Sr[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { Dp[j] = (j < ns) ? par(sl.Dp + ss + j) : 0.0; Sr[j] = 0.0; }
+  const double* y0 = A.y0 + (A.y0_batched ? b * S : 0);
+  double* Yout = A.Y + b * (size_t)A.T * S;
+  double y[NR];
+  y[0] = own ? y0[st] : 0.0;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) y[1 + m] = (own && m < nst) ? y0[st + 1 + m] : 0.0;
+  auto write_row = [&](int row) {
+    if (!own) return;
+    double* o = Yout + (size_t)row * S + st;
+    o[0] = y[0];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) if (m < nst) o[1 + m] = y[1 + m];
+  };
+  write_row(0);
+
+  auto set_bucket = [&](const int jb) {
+    __syncthreads();
+    for (int k = tid; k < n.n_K; k += nt) Kt[k] = n.kin_Kmat[(size_t)k * n.n_grid + jb] * (A.x_is_raw ? softplus(xb[sl.ck + k]) : xb[sl.ck + k]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double acc = 0.0;
+      if (j < ns) for (int q = n.W_indptr[ss + j]; q < n.W_indptr[ss + j + 1]; ++q) acc += n.W_data[q] * Kt[n.W_indices[q]];
+      Sr[j] = acc;
+    }
+  };
+  auto loss_of = [&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    double l = 0.0;
+    static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr ((m >> j) & 1) l += Ei + Dp[j] + Di; else l += Sr[j]; });
+    if constexpr (m == 0) l += Di;
+    return l;
+  };
+  int buf = 0;
+  auto rhs_block = [&](const double (&Y)[NR], double (&f)[NR]) {
+    double tot = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) tot += Y[1 + m];                  // the combinatorial RHS ignores driver_map (jacspeedup.py:319-327)
+    if (own) Pv[buf * N + i] = tot;
+    __syncthreads();
+    double acc = 0.0;
+    for (int e = tf0; e < tf1; ++e) acc += tf_dat[e] * Pv[buf * N + tf_idx[e]];
+    buf ^= 1;
+    double v = acc * tfdeg_inv;
+    v = v * net_rcp(1.0 + fabs(v));
+    f[0] = synth_rate_fast(Ai, ts, v) - Bi * Y[0];
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double a = (m == 0) ? Ci * Y[0] : 0.0;
+      static_for<NB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr ((m >> j) & 1) a = __builtin_fma(Sr[j], Y[1 + (m ^ (1 << j))], a);
+        else a = __builtin_fma(Ei, Y[1 + (m | (1 << j))], a);
+      });
+      f[1 + m] = a - loss_of(mc) * Y[1 + m];
+    });
+  };
+  double winvR = 1.0, gB = 1.0, dinv[NM], dg[NM];
+  auto factor = [&](const double g) {
+    gB = g + Bi;
+    winvR = net_rcp(gB);
+    static_for<NM>([&](auto mc) { constexpr int m = decltype(mc)::value; dg[m] = g + loss_of(mc); dinv[m] = net_rcp(dg[m]); });
+  };
+  // x = P^-1 r : forward sweep (ascending masks), rescale, backward sweep (descending masks)
+  auto block_solve = [&](const double (&r)[NR], double (&x)[NR]) {
+    const double xR = r[0] * winvR;
+    x[0] = xR;
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double a = r[1 + m] + ((m == 0) ? Ci * xR : 0.0);
+      static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr ((m >> j) & 1) a = __builtin_fma(Sr[j], x[1 + (m ^ (1 << j))], a); });
+      x[1 + m] = a * dinv[m];
+    });
+    static_for<NM>([&](auto mc) {
+      constexpr int m = NM - 1 - decltype(mc)::value;
+      double a = x[1 + m] * dg[m];
+      static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr (!((m >> j) & 1)) a = __builtin_fma(Ei, x[1 + (m | (1 << j))], a); });
+      x[1 + m] = a * dinv[m];
+    });
+  };
+  // out = P x = (D_g - F) D_g^-1 (D_g - K) x   (stage 1 only)
+  auto apply_P = [&](const double (&x)[NR], double (&out)[NR]) {
+    double t2[NM];
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double a = dg[m] * x[1 + m];
+      static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr (!((m >> j) & 1)) a = __builtin_fma(-Ei, x[1 + (m | (1 << j))], a); });
+      t2[m] = a * dinv[m];
+    });
+    out[0] = gB * x[0];
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double a = dg[m] * t2[m] - ((m == 0) ? Ci * x[0] : 0.0);
+      static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr ((m >> j) & 1) a = __builtin_fma(-Sr[j], t2[m ^ (1 << j)], a); });
+      out[1 + m] = a;
+    });
+  };
+  double* const mypark = park + tid;
+  auto park_ld = [&](int slot, int row) { return mypark[(size_t)(slot * NR + row) * nt]; };
+  auto park_st = [&](int slot, int row, double x) { mypark[(size_t)(slot * NR + row) * nt] = x; };
+
+  __syncthreads();
+  int status = PK_ST_OK, nacc = 0, nrej = 0;
+  double tc = A.t0;
+  int jb = net_bucket(tc, n.kin_grid, n.n_grid);
+  set_bucket(jb);
+  double h;
+  {
+    double f[NR];
+    rhs_block(y, f);
+    auto q = [&](double v, double yv) { return fabs(v) / (A.atol + A.rtol * fabs(yv)); };
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) if (own && k < 1 + nst) { d0 = fmax(d0, q(y[k], y[k])); d1 = fmax(d1, q(f[k], y[k])); }
+    d0 = block_max(d0, red); d1 = block_max(d1, red);
+    h = (d0 > 1e-5 && d1 > 1e-5) ? 0.01 * d0 / d1 : 1e-6;
+    if (A.h0 > 0.0) h = A.h0;
+    if (!(h > 0.0) || h != h) h = 1e-6;
+  }
+  const bool rms = A.err_rms;
+  bool after_reject = false;
+  for (int si = 0; si < A.n_stops && status == PK_ST_OK; ++si) {
+    const double te = stops[si];
+    while (true) {
+      if (nacc + nrej >= A.max_steps) { status |= PK_ST_MAXSTEPS; break; }
+      const bool last = (tc + 1.0001 * h >= te);
+      const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
+      if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; break; }
+      const double g = net_rcp(hs * GAM);
+      factor(g);
+      double Y[NR], w[NR], v[NR], sb[NR], se[NR];
+      // ---- stage 1: Y_1 = y_n ;  h A~ y = h (g y - P y)
+      rhs_block(y, w);
+      apply_P(y, v);
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        w[k] *= hs; v[k] = hs * (g * y[k] - v[k]);
+        sb[k] = B[0] * w[k]; se[k] = EB[0] * w[k];
+      }
+      static_for<4>([&](auto ic) {
+        constexpr int ii = decltype(ic)::value;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) park_st(ii, k, y[k] + AE[ii + 1][0] * w[k] + DI[ii + 1][0] * v[k]);
+      });
+      static_for<5>([&](auto sc) {
+        constexpr int s = 2 + decltype(sc)::value;
+        double gr[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          double rk;
+          if constexpr (s == 2) rk = y[k] + AE[0][0] * w[k] + DI[0][0] * v[k]; else rk = park_ld(s - 3, k);
+          gr[k] = g * rk;
+        }
+        block_solve(gr, Y);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) v[k] = __builtin_fma(-hs, gr[k], (1.0 / GAM) * Y[k]);
+        rhs_block(Y, w);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          w[k] *= hs;
+          if constexpr (s != 2) { sb[k] = __builtin_fma(B[s - 1], w[k], sb[k]); se[k] = __builtin_fma(EB[s - 1], w[k], se[k]); }
+        }
+        static_for<4>([&](auto ic) {
+          constexpr int ii = decltype(ic)::value;
+          if constexpr (ii + 3 > s) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) park_st(ii, k, park_ld(ii, k) + AE[ii + 1][s - 1] * w[k] + DI[ii + 1][s - 1] * v[k]);
+          }
+        });
+      });
+      auto q = [&](double ev, double ya, double yb) { return fabs(ev) * net_rcp(A.atol + A.rtol * fmax(fabs(ya), fabs(yb))); };
+      double e = 0.0;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        sb[k] += y[k];
+        if (own && k < 1 + nst) e = err_acc(e, q(se[k], y[k], sb[k]), rms);
+      }
+      const double err = err_reduce(e, rms, S, red);
+      if (err != err || err > 1e300) {
+        ++nrej; after_reject = true; h = 0.1 * hs;
+        double bad = (nonfinite(Ai) || nonfinite(Bi) || nonfinite(Ci) || nonfinite(Di) || nonfinite(Ei) || nonfinite(ts)) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) if (nonfinite(y[k])) bad = 1.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) if (nonfinite(Dp[j]) || nonfinite(Sr[j])) bad = 1.0;
+        if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
+        continue;
+      }
+      double fac = sqrt(sqrt(err)) * (1.0 / 0.9);
+      fac = fmax(1.0 / 6.0, fmin(5.0, fac));
+      double hnew = hs * net_rcp(fac);
+      if (err <= 1.0) {
+        ++nacc;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) y[k] = sb[k];
+        tc += hs;
+        if (after_reject) hnew = fmin(hnew, hs);
+        after_reject = false;
+        if (last) { tc = te; h = (hs < h) ? fmax(hnew, h) : hnew; break; }
+        h = hnew;
+      } else {
+        ++nrej; after_reject = true;
+        h = hnew;
+      }
+    }
+    if (status != PK_ST_OK) break;
+    const int row = stop_out[si];
+    if (row >= 0) write_row(row);
+    const int jn = net_bucket(tc, n.kin_grid, n.n_grid);
+    if (jn != jb) { jb = jn; set_bucket(jb); }
+  }
+  if (status != PK_ST_OK && own) {
+    const double qnan = __builtin_nan("");
+    for (int si = 0; si < A.n_stops; ++si) {
+      const int row = stop_out[si];
+      if (row >= 0 && !(stops[si] <= tc)) { double* o = Yout + (size_t)row * S + st; for (int k = 0; k < 1 + nst; ++k) o[k] = qnan; }
+    }
+  }
+  if (tid == 0) {
+    if (A.status) A.status[b] = status;
+    if (A.n_steps) { A.n_steps[2 * b] = nacc; A.n_steps[2 * b + 1] = nrej; }
+  }
+}
+
 __host__ inline size_t net_solve_ark_lds_bytes(const NetDev& n, int nnzT, int rows, int threads) {
   return ((size_t)n.n_K + 2 * (size_t)n.N + 24 + nnzT + (nnzT + 1) / 2 + net_ark_park_doubles(rows, threads)) * 8;
 }

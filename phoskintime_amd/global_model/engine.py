@@ -149,7 +149,7 @@ class NetworkEngine:
         if rtol is None or atol is None:
             # parity-grade defaults (worst band error over every reference-run fixture <= 0.3, tools/gpu_norm_scan.py): the order-4 method
             # at the reference optimiser's own tolerances (config.toml:403-404), the order-3 method at 1e-7 / 1e-9
-            ark = self.ark_eligible() and method in ("auto", "ark") and kernel != "lds"
+            ark = (self.ark_eligible() and method == "auto" or method == "ark") and kernel != "lds"
             rtol = (1e-8 if ark else 1e-7) if rtol is None else rtol
             atol = (1e-8 if ark else 1e-9) if atol is None else atol
         if method not in ("auto", "ark", "rosw", "dp5"):
@@ -183,8 +183,9 @@ class NetworkEngine:
         return Y, status, nsteps
 
     def ark_eligible(self) -> bool:
-        """Whether pk_network_simulate_batch runs the order-4 additive integrator on this network (one thread per protein: topologies
-        0 / 1 / 4, at most 8 sites per protein, N <= 256)."""
+        """Whether pk_network_simulate_batch runs the order-4 additive integrator on this network BY DEFAULT (one thread per protein:
+        topologies 0 / 1 / 4, N <= 256, at most 8 sites per protein).  The combinatorial topology has the kernel too (method="ark",
+        <= 3 sites) but its order-3 kernel is faster per result, so it is not the default there."""
         return self.model != 2 and self.N <= 256 and (int(self._keep[2].max()) if self.N else 0) <= 8
 
     # ------------------------------------------------------------------ loss / objectives

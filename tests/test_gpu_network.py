@@ -480,6 +480,12 @@ def test_combinatorial_blocks_beyond_three_sites():
     assert not sa.cpu().numpy().any() and not sb.cpu().numpy().any()
     assert band(Yb.cpu().numpy(), Ya.cpu().numpy()) <= 0.2
     assert band(Yb.cpu().numpy()[:2], g["Y_tight"]) <= 0.5
+    # the additive order-4 kernel exists for this topology too (on request: its step costs more than it saves here): its implicit operator
+    # is the approximate factorisation itself; same trajectories, >= 2x fewer steps
+    Yk, sk, nk = e3.simulate_batch(X3, g["t_eval"], rtol=1e-8, atol=1e-8, method="ark")
+    Yr, sr, nr = e3.simulate_batch(X3, g["t_eval"], rtol=1e-8, atol=1e-8, method="rosw")
+    assert not sk.cpu().numpy().any() and band(Yk.cpu().numpy()[:2], g["Y_tight"]) <= 0.3
+    assert 2 * int(nk[:, 0].sum()) <= int(nr[:, 0].sum())
     e3.close()
 
 
@@ -665,7 +671,9 @@ def test_large_network_against_the_reference_run(f):
     assert e_par <= 0.1 and e_opt <= 0.3 and e_rms <= 0.5
     assert e_opt <= max(0.2, 2.5 * ref_own)                     # same nominal tolerance: the reference run's own accuracy class
     if eng.ark_eligible():
-        assert 4 * int(no[0, 0]) <= int(npp[0, 0])              # >= 2x fewer steps at 1e-8 with parity held (measured 5-6x)
+        # >= 2x fewer steps at 1e-8 with parity held -- measured 4.2-5.1x (topologies 0 / 1 / 4) and 2.7x (combinatorial:
+        # its approximate block factorisation leaves a defect to the explicit tableau)
+        assert (2.5 if int(g["model"]) == 2 else 4) * int(no[0, 0]) <= int(npp[0, 0])
     assert int(nrr[0, 0]) <= 0.7 * int(npp[0, 0])
     for k in range(2):                                                                 # both reference runs at 1e-8: within its error + ours
         assert band(Yo[k].cpu().numpy(), g["Y_lsoda8"][k]) <= ref_own + e_opt + 1.0

@@ -13,15 +13,16 @@ def main():
         X = synthetic.random_candidates(net, B, seed=1)
         t_eval = np.unique(np.concatenate([net['kin_grid'], [15.0]]))
         Xd = torch.as_tensor(X, device='cuda')
-        for rtol, atol in ((1e-5, 1e-7), (1e-7, 1e-9)):
-            eng.simulate_batch(Xd[:64], t_eval, rtol=rtol, atol=atol); torch.cuda.synchronize()
+        for rtol, atol in ((1e-5, 1e-7), (1e-7, 1e-9), (1e-8, 1e-8)):
+          for method in ("rosw", "auto"):
+            eng.simulate_batch(Xd[:64], t_eval, rtol=rtol, atol=atol, method=method); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            Y, st, ns = eng.simulate_batch(Xd, t_eval, rtol=rtol, atol=atol)
+            Y, st, ns = eng.simulate_batch(Xd, t_eval, rtol=rtol, atol=atol, method=method)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             nsc = ns.cpu().numpy()
-            print('model %d S %d n_var %d B %d rtol %.0e: %.1f ms  %.0f candidates/s  steps mean %.0f max %d rej mean %.0f  flagged %d' % (
-                model, eng.S, eng.n_var, B, rtol, dt * 1e3, B / dt, nsc[:, 0].mean(), nsc[:, 0].max(), nsc[:, 1].mean(), int((st != 0).sum())), flush=True)
+            print('model %d S %d n_var %d B %d rtol %.0e atol %.0e %s: %.1f ms  %.0f candidates/s  steps mean %.0f max %d rej mean %.0f  flagged %d' % (
+                model, eng.S, eng.n_var, B, rtol, atol, method, dt * 1e3, B / dt, nsc[:, 0].mean(), nsc[:, 0].max(), nsc[:, 1].mean(), int((st != 0).sum())), flush=True)
         if model == 0 and '--oracle' in sys.argv:
             from oracle import network_models as nm
             onet = nm.Network(model=model, N=eng.N, n_K=eng.n_K, total_sites=eng.total_sites, S=eng.S, **{k: net[k] for k in (
