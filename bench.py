@@ -367,6 +367,64 @@ def network_leg(dev):
     return out
 
 
+def morris_leg(dev):
+    """BASELINE config 4: Morris screening of the network, 128 trajectories; like the reference (global_model/sensitivity.py:196-215) EVERY
+    entry of the fitted parameter set is varied (D = n_var; BASELINE's "200 params" is a smaller design of the same shape)."""
+    from phoskintime_amd.global_model import NetworkEngine, synthetic
+    from phoskintime_amd.global_model import sensitivity as gs
+    from phoskintime_amd.global_model import config as gcfg
+    gfile = ROOT / "tests" / "golden" / "netlarge_m0.npz"
+    if gfile.exists():
+        g = np.load(gfile); eng = NetworkEngine.from_npz(g)
+        base = eng.pack_params(g["c_k"][0], g["A_i"][0], g["B_i"][0], g["C_i"][0], g["D_i"][0], g["Dp_i"][0], g["E_i"][0], g["tf_scale"][0])
+    else:
+        net = synthetic.make_network(model=0); eng = NetworkEngine(**net); base = synthetic.default_candidate(net)
+    nK, N, sites = eng.n_K, eng.N, eng.total_sites
+    cut = np.cumsum([nK, N, N, N, N, sites, N])
+    fitted = dict(zip(("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i"), np.split(base[:-1], cut[:-1]))); fitted["tf_scale"] = float(base[-1])
+    tp, tr = gcfg.TIME_POINTS_PROTEIN, gcfg.TIME_POINTS_RNA
+    gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, trajectories=2, num_levels=40, seed=1)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    out = gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, trajectories=128, num_levels=40, seed=3)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t1
+    nsim = out["Y"].size
+    eng.close()
+    return {"workload": "BASELINE config 4: Morris screening of the N=%d / S=%d network, 128 trajectories x (D = %d varied parameters + 1) = %d simulations at the "
+                        "settings of simulate_and_measure -> fold-change observables -> total_signal -> elementary effects on the GPU" % (N, eng.S, eng.n_var, nsim),
+            "wall_s": dt, "simulations_per_s": nsim / dt, "flagged": int((out["status"] != 0).sum()), "finite_mu_star": bool(np.isfinite(out["Si"]["mu_star"]).all())}
+
+
+def lm_leg():
+    """The rows-batched bounded Levenberg-Marquardt driver (paramest.normest's fits) at two sizes, each with residuals / Jacobian columns /
+    normal equations formed on the GPU and on round 1's path (every `flat` vector over PCIe, numpy algebra); "auto" picks by transfer size."""
+    from phoskintime_amd import batch
+    from phoskintime_amd.paramest import fit_rows_batch, multistart_candidates
+    out = {}
+    for label, n, rows, iters in (("multistart_48_starts_distmod_n8", 8, 48, 60), ("lambda_scan_480_rows_distmod_n30", 30, 480, 12)):
+        P, S = 4 + 2 * n, n + 2
+        rng = np.random.default_rng(20260515 + 9)
+        th_true = rng.uniform(0.2, 2.0, P)
+        flat = batch.solve_ode_batch("distmod", th_true[None], np.ones(S), n, TGRID, want_sol=False).flat[0].cpu().numpy()
+        target = np.abs(flat * (1 + 0.02 * rng.standard_normal(flat.size)))
+        lb, ub = np.zeros(P), np.full(P, 20.0)
+        P0 = multistart_candidates("BENCH", rng.uniform(lb, ub), lb, ub, n_starts=rows)
+        leg = {"rows": rows, "P": P, "residuals": int(flat.size), "flat_bytes_per_jacobian": rows * P * flat.size * 8}
+        for name, dev_alg in (("device_algebra", True), ("host_algebra_round1", False)):
+            fit_rows_batch("distmod", n, TGRID, P0[:4], np.ones(S), target, bounds=(lb, ub), max_iter=2, device_algebra=dev_alg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fit = fit_rows_batch("distmod", n, TGRID, P0, np.ones(S), target, bounds=(lb, ub), max_iter=iters, device_algebra=dev_alg)
+            torch.cuda.synchronize()
+            leg[name] = {"wall_ms": 1e3 * (time.perf_counter() - t1), "iterations": fit.n_iter, "solves": fit.n_solves, "launches": fit.n_launches,
+                         "best_cost": float(fit.cost.min())}
+        leg["auto_picks"] = "device" if rows * P * flat.size * 8 > (2 << 20) else "host"
+        out[label] = leg
+    out["workload"] = "bounded LM fits of models.distmod (2 % noise on the target), forward-difference Jacobian columns on the throughput kernels"
+    return out
+
+
 def secondary_legs(args, dev, tt, cpu):
     """Evidence beside the metric (never the metric): machine peaks measured here, config 1 latency, config 5 network path, other sizes."""
     from phoskintime_amd import batch, models
@@ -401,6 +459,14 @@ def secondary_legs(args, dev, tt, cpu):
             res["network_config5"] = network_leg(dev)
         except Exception as e:  # never let a secondary line break the metric
             res["network_config5"] = {"error": repr(e)}
+        try:
+            res["network_config4"] = morris_leg(dev)
+        except Exception as e:
+            res["network_config4"] = {"error": repr(e)}
+    try:
+        res["lm_fit"] = lm_leg()
+    except Exception as e:
+        res["lm_fit"] = {"error": repr(e)}
     try:
         other = {}
         for label, mdl, nn, Bo in (("config1_size_distmod_n4_B65536", "distmod", 4, 65536), ("config2_succmod_n14_B4096", "succmod", 14, 4096),

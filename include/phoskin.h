@@ -155,7 +155,8 @@ int pk_jacobian_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
 /* Steady state y* of dy/dt = J(theta) y + b(theta) = 0 for B parameter vectors: y_ss [B,S] (device), status [B] (or NULL;
  * PK_ST_NONFINITE + a NaN row when J is singular, e.g. no degradation).  Generalises steady.initial_condition(num_psites)
  * (steady/initdist.py:9-50, initsucc.py:9-55, initrand.py:9-77: SLSQP on the steady-state equations with every rate fixed to 1,
- * called once per protein at paramest/core.py:83) to per-replica theta; S <= 64. */
+ * called once per protein at paramest/core.py:83) to per-replica theta.  Beyond 64 states one workgroup owns a replica: closed form (distmod),
+ * cyclic reduction (succmod), symmetric Gauss-Seidel on the n-cube (randmod, n_sites <= 12; PK_ST_MAXSTEPS + NaN row if it does not converge). */
 int pk_steady_state_protein_batch(pk_ctx*, int model, int n_sites, int64_t B, const double* theta, double* y_ss, int32_t* status);
 
 /* Morris screening without a host round trip (reference: SALib morris.sample / morris.analyze as called at

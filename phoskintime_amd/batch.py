@@ -9,6 +9,7 @@ stream and (in ``phoskintime_amd.distributed``) the RCCL all-gather; every kerne
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from dataclasses import dataclass
 from typing import Optional, Sequence, Union
 
@@ -42,16 +43,32 @@ def model_id(model: Union[int, str]) -> int:
     return int(model)
 
 
+# shapes are pure functions of small integers and sit on the one-theta-per-call path (models.solve_ode): memoised
+@functools.lru_cache(maxsize=4096)
+def _n_states(mid: int, n: int) -> int:
+    return _shape_or_raise(_capi.load().pk_protein_n_states(mid, n))
+
+
+@functools.lru_cache(maxsize=4096)
+def _n_params(mid: int, n: int) -> int:
+    return _shape_or_raise(_capi.load().pk_protein_n_params(mid, n))
+
+
+@functools.lru_cache(maxsize=4096)
+def _flat_len(mid: int, n: int, T: int) -> int:
+    return _shape_or_raise(_capi.load().pk_protein_flat_len(mid, n, T))
+
+
 def n_states(model, n_sites: int) -> int:
-    return _shape_or_raise(_capi.load().pk_protein_n_states(model_id(model), int(n_sites)))
+    return _n_states(model_id(model), int(n_sites))
 
 
 def n_params(model, n_sites: int) -> int:
-    return _shape_or_raise(_capi.load().pk_protein_n_params(model_id(model), int(n_sites)))
+    return _n_params(model_id(model), int(n_sites))
 
 
 def flat_len(model, n_sites: int, T: int) -> int:
-    return _shape_or_raise(_capi.load().pk_protein_flat_len(model_id(model), int(n_sites), int(T)))
+    return _flat_len(model_id(model), int(n_sites), int(T))
 
 
 def _shape_or_raise(v: int) -> int:

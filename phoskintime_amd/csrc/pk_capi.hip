@@ -307,7 +307,15 @@ int pk_steady_state_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, 
   if (B == 0) return PK_OK;
   if (!theta || !y_ss) return fail(c, PK_ERR_ARG, "null pointer");
   const int S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites);
-  if (S > 64) return fail(c, PK_ERR_UNSUPPORTED, "steady state: S <= 64 (distmod / succmod n_sites <= 62, randmod n_sites <= 5)");
+  if (S > 64) {                                  // one workgroup per replica (pk_wide.hpp): closed form / cyclic reduction / Gauss-Seidel on the n-cube
+    if (B > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+    PK_HIP(c, hipSetDevice(c->device));
+    hipError_t e = pk::launch_wide_steady(model, theta, y_ss, status, (long long)B, n_sites, S, P, c->stream);
+    if (e == hipErrorInvalidValue) return fail(c, PK_ERR_UNSUPPORTED, "steady state: randmod n_sites <= 12 (two LDS vectors of 2^n doubles + the level table)");
+    PK_HIP(c, e);
+    PK_HIP(c, hipGetLastError());
+    return PK_OK;
+  }
   const int G = group_width(S);
   const long long rpb = 256 / G, nblk = (B + rpb - 1) / rpb;
   if (nblk > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");

@@ -61,6 +61,32 @@ hipError_t launch_wide_rand(const SolveArgs& a, double* scratch, hipStream_t st)
   return hipSuccess;
 }
 
+// steady state beyond 64 states; returns hipErrorInvalidValue when the system does not fit LDS (randmod n_sites >= 13)
+hipError_t launch_wide_steady(int model, const double* theta, double* yss, int32_t* status, long long B, int n, int S, int P, hipStream_t st) {
+  hipError_t e;
+  if (model == M_RAND) {
+    const size_t lds = wide_steady_rand_lds_bytes(n);
+    if (lds > kLdsMax) return hipErrorInvalidValue;
+    static std::atomic<uint64_t> ready{0};
+    if ((e = allow_lds(wide_steady_rand_kernel, ready)) != hipSuccess) return e;
+    hipLaunchKernelGGL(wide_steady_rand_kernel, dim3((unsigned)B), dim3(S <= 129 ? 64 : 256), lds, st, theta, yss, status, B, n, S, P);
+    return hipSuccess;
+  }
+  const size_t lds = wide_steady_chain_lds_bytes(S);
+  if (lds > kLdsMax) return hipErrorInvalidValue;
+  const int nt = S <= 64 ? 64 : S <= 128 ? 128 : 256;
+  if (model == M_DIST) {
+    static std::atomic<uint64_t> ready{0};
+    if ((e = allow_lds(wide_steady_chain_kernel<M_DIST>, ready)) != hipSuccess) return e;
+    hipLaunchKernelGGL((wide_steady_chain_kernel<M_DIST>), dim3((unsigned)B), dim3(nt), lds, st, theta, yss, status, B, n, S, P);
+  } else {
+    static std::atomic<uint64_t> ready{0};
+    if ((e = allow_lds(wide_steady_chain_kernel<M_SUCC>, ready)) != hipSuccess) return e;
+    hipLaunchKernelGGL((wide_steady_chain_kernel<M_SUCC>), dim3((unsigned)B), dim3(nt), lds, st, theta, yss, status, B, n, S, P);
+  }
+  return hipSuccess;
+}
+
 void launch_chain_rhs_wide(int model, const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t st) {
   const long long nblk = (B * S + 255) / 256;
   if (model == M_DIST) hipLaunchKernelGGL((chain_rhs_wide_kernel<M_DIST>), dim3((unsigned)nblk), dim3(256), 0, st, theta, y, dydt, B, n, S, P);

@@ -33,6 +33,7 @@ hipError_t launch_wide_chain(const SolveArgs&, int model, hipStream_t);     // L
 bool wide_rand_in_lds(int n_sites);                                         // randmod n >= 7: 9 LDS vectors of 2^n + 1 doubles (n <= 10 / 11)
 size_t wide_rand_scratch_bytes(int n_sites, long long B);                   // 0 when the vectors fit LDS
 hipError_t launch_wide_rand(const SolveArgs&, double* scratch, hipStream_t);   // ROS34PW2-W on the n-cube
+hipError_t launch_wide_steady(int model, const double* theta, double* yss, int32_t* status, long long B, int n, int S, int P, hipStream_t);
 void launch_chain_rhs_wide(int model, const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t);
 void launch_chain_jac_wide(int model, const double* theta, double* J, long long B, int n, int S, int P, hipStream_t);
 void launch_rand_rhs_wide(const double* theta, const double* y, double* dydt, long long B, int n, int S, int P, hipStream_t);

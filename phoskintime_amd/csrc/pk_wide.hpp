@@ -540,4 +540,142 @@ __global__ void chain_jac_wide_kernel(const double* __restrict__ theta, double* 
   Jr[row] = c.dg;
 }
 
+
+// =====================================================================================================================================
+// Steady states y* of dy/dt = J y + b = 0 for the wide systems (pk_steady_state_protein_batch beyond 64 states).
+//   distmod: closed form of the arrow system;  succmod: the tridiagonal system -J y = b by cyclic reduction in LDS;
+//   randmod: -J y = b on the n-cube by symmetric Gauss-Seidel sweeps over the popcount levels (an M-matrix with strictly dominant columns
+//   whenever the degradation rates are positive: the iteration converges; tolerance 1e-13 relative, budget 200 000 sweeps).
+// A singular J (no degradation) gives non-finite values: PK_ST_NONFINITE and a NaN row; an exhausted budget: PK_ST_MAXSTEPS and a NaN row.
+__host__ __device__ inline size_t wide_steady_chain_lds_bytes(int S) { return ((size_t)11 * S + 24) * sizeof(double); }
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void wide_steady_chain_kernel(const double* __restrict__ theta, double* __restrict__ yss, int32_t* __restrict__ status,
+                                                                const long long B, const int n, const int S, const int P) {
+  extern __shared__ __align__(16) double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const long long rep = blockIdx.x;
+  if (rep >= B) return;
+  const double* __restrict__ th = theta + rep * P;
+  double* c1 = lds;       double* dgv = c1 + S;    double* c2 = dgv + S;
+  double* pa = c2 + S;    double* pb = pa + S;     double* pc = pb + S;    double* pr = pc + S;
+  double* qa = pr + S;    double* qb = qa + S;     double* qc = qb + S;    double* qr = qc + S;
+  double* red = qr + S;
+  for (int row = tid; row < S; row += nt) { const RowCoef c = load_row<MODEL>(th, n, S, row); c1[row] = c.c1; dgv[row] = c.dg; c2[row] = c.c2; }
+  __syncthreads();
+  double* x = pr;                                               // result vector
+  if constexpr (MODEL == M_DIST) {
+    // A - B R = 0 ; S_i P - (1 + D_i) X_i = 0 ; C R - Dsum P + sum X_i = 0
+    double loc = 0.0;
+    for (int row = 2 + tid; row < S; row += nt) { const double cw = c1[row] / (-dgv[row]); pa[row] = cw; loc += cw; }
+    const double Scw = wg_sum(loc, red);
+    const double R = th[0] / (-dgv[0]);
+    const double Pv = c2[1] * R / (-dgv[1] - Scw);
+    __syncthreads();
+    for (int row = tid; row < S; row += nt) x[row] = (row == 0) ? R : (row == 1 ? Pv : pa[row] * Pv);
+    __syncthreads();
+  } else {
+    double *sa = pa, *sb = pb, *sc = pc, *sr = pr, *da = qa, *db = qb, *dc = qc, *dr = qr;
+    for (int row = tid; row < S; row += nt) { sa[row] = -c1[row]; sb[row] = -dgv[row]; sc[row] = -c2[row]; sr[row] = (row == 0) ? th[0] : 0.0; }
+    __syncthreads();
+    for (int d = 1; d < S; d <<= 1) {
+      for (int row = tid; row < S; row += nt) {
+        const int lo = row - d, hi = row + d;
+        double na = 0.0, nc = 0.0, nb = sb[row], nr = sr[row];
+        if (lo >= 0) { const double al = -sa[row] / sb[lo]; na = al * sa[lo]; nb = __builtin_fma(al, sc[lo], nb); nr = __builtin_fma(al, sr[lo], nr); }
+        if (hi < S) { const double ga = -sc[row] / sb[hi]; nc = ga * sc[hi]; nb = __builtin_fma(ga, sa[hi], nb); nr = __builtin_fma(ga, sr[hi], nr); }
+        da[row] = na; db[row] = nb; dc[row] = nc; dr[row] = nr;
+      }
+      __syncthreads();
+      double* t;
+      t = sa; sa = da; da = t; t = sb; sb = db; db = t; t = sc; sc = dc; dc = t; t = sr; sr = dr; dr = t;
+    }
+    for (int row = tid; row < S; row += nt) c1[row] = sr[row] / sb[row];       // c1 is free by now
+    __syncthreads();
+    x = c1;
+  }
+  double bad = 0.0;
+  for (int row = tid; row < S; row += nt) if (nonfinite(x[row])) bad = 1.0;
+  bad = wg_max(bad, red);
+  for (int row = tid; row < S; row += nt) yss[rep * S + row] = (bad != 0.0) ? __builtin_nan("") : x[row];
+  if (tid == 0 && status) status[rep] = (bad != 0.0) ? PK_ST_NONFINITE : PK_ST_OK;
+}
+
+__host__ __device__ inline size_t wide_steady_rand_lds_bytes(int n) {
+  const size_t NM = (size_t)1 << n;
+  return ((size_t)2 * (NM + 1) + n + 24) * sizeof(double) + (NM + (n + 2) + 21 * 21) * sizeof(int);
+}
+
+__global__ __launch_bounds__(256) void wide_steady_rand_kernel(const double* __restrict__ theta, double* __restrict__ yss, int32_t* __restrict__ status,
+                                                               const long long B, const int n, const int S, const int P) {
+  extern __shared__ __align__(16) double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int NM = 1 << n;
+  const long long rep = blockIdx.x;
+  if (rep >= B) return;
+  const double* __restrict__ th = theta + rep * P;
+  double* x = lds;            double* loss = x + S;       double* Sr = loss + S;      double* red = Sr + n;
+  int* lvl = reinterpret_cast<int*>(red + 24);   int* binom = lvl + (n + 2);   int* ord = binom + 21 * 21;
+  const double cA = th[0], cB = th[1], cC = th[2], cD = th[3];
+  if (tid == 0) {
+    for (int a = 0; a <= 20; ++a) for (int b = 0; b <= 20; ++b) binom[a * 21 + b] = (b == 0) ? 1 : (a == 0 ? 0 : binom[(a - 1) * 21 + b - 1] + binom[(a - 1) * 21 + b]);
+    lvl[0] = 0;
+    for (int L = 0; L <= n; ++L) lvl[L + 1] = lvl[L] + binom[n * 21 + L];
+  }
+  for (int j = tid; j < n; j += nt) Sr[j] = th[4 + j];
+  __syncthreads();
+  double sumS = 0.0;
+  for (int j = 0; j < n; ++j) sumS += Sr[j];
+  const double R = cA / cB;
+  for (int m = tid; m < NM; m += nt) {
+    int kk = __popc(m), rank = 0;
+    { int c = kk; for (int j = n - 1; j >= 0 && c > 0; --j) if ((m >> j) & 1) { rank += binom[j * 21 + c]; --c; } }
+    ord[lvl[kk] + rank] = m;
+    double l;
+    if (m == 0) l = cD + sumS;
+    else {
+      const int lsb = __builtin_ctz(m);
+      double o = 0.0;
+      for (int j = 0; j < n; ++j) o += ((m >> j) & 1) ? 1.0 : Sr[j < lsb ? j : lsb];
+      l = o + th[4 + n + m - 1];
+    }
+    loss[1 + m] = l;
+    x[1 + m] = 0.0;
+  }
+  if (tid == 0) x[0] = R;
+  __syncthreads();
+  // one state update: x_m = (source_m + S[lsb m] sum_{j in m} x_{m ^ j} + sum_{j not in m} x_{m | j}) / loss_m ; returns |change| / scale
+  auto relax = [&](const int m) {
+    double lo = 0.0, hi = 0.0;
+    for (int mm = m; mm; mm &= mm - 1) lo += x[1 + (m ^ (mm & -mm))];
+    for (int mm = ~m & (NM - 1); mm; mm &= mm - 1) hi += x[1 + (m | (mm & -mm))];
+    const double src = (m == 0) ? cC * R : Sr[__builtin_ctz(m)] * lo;
+    const double xn = (src + hi) / loss[1 + m];
+    const double d = fabs(xn - x[1 + m]) / (fabs(xn) + 1e-300);
+    x[1 + m] = xn;
+    return d;
+  };
+  int st = PK_ST_MAXSTEPS;
+  for (int it = 0; it < 200000; ++it) {
+    double dmax = 0.0;
+    for (int L = 0; L <= n; ++L) {
+      for (int idx = lvl[L] + tid; idx < lvl[L + 1]; idx += nt) { const double d = relax(ord[idx]); dmax = (d > dmax || d != d) ? d : dmax; }
+      __syncthreads();
+    }
+    for (int L = n - 1; L >= 0; --L) {
+      for (int idx = lvl[L] + tid; idx < lvl[L + 1]; idx += nt) { const double d = relax(ord[idx]); dmax = (d > dmax || d != d) ? d : dmax; }
+      __syncthreads();
+    }
+    dmax = wg_max(dmax, red);
+    if (dmax != dmax) { st = PK_ST_NONFINITE; break; }
+    if (dmax <= 1e-13) { st = PK_ST_OK; break; }
+  }
+  double bad = (st != PK_ST_OK) ? 1.0 : 0.0;
+  for (int row = tid; row < S; row += nt) if (nonfinite(x[row])) bad = 1.0;
+  bad = wg_max(bad, red);
+  if (bad != 0.0 && st == PK_ST_OK) st = PK_ST_NONFINITE;
+  for (int row = tid; row < S; row += nt) yss[rep * S + row] = (bad != 0.0) ? __builtin_nan("") : x[row];
+  if (tid == 0 && status) status[rep] = st;
+}
+
 }  // namespace pk

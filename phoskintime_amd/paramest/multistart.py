@@ -70,7 +70,7 @@ class RowsFit:
 
 
 def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None,
-                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra: bool = True, **solver_kw) -> RowsFit:
+                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra="auto", **solver_kw) -> RowsFit:
     """R independent bounded least-squares problems in lockstep: row k fits ``[flat(p) ; lam_k / P * p**2]`` to ``[target_k ; 0]`` with
     weights ``sigma_k`` from the start point ``P0[k]``.  Rows may be the starts of one multistart fit, the (lambda, weight) grid of
     ``find_best_lambda``, bootstrap replicates, different proteins of the same size -- or any mix.
@@ -79,10 +79,13 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     lam scalar or [R]; bounds (lb, ub), each [P] or [R, P].
 
     Every iteration is ONE launch for the Jacobian columns (n_active * P replicas) plus one launch per damping round for the trial
-    points.  ``device_algebra=True`` (default): residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU
-    (torch ops on the `flat` tensors the kernel wrote); per iteration and row only P x P + P doubles come back and a P-vector of trial
-    parameters goes up -- round 1 moved every ``flat`` vector (n_active * (1 + P) x Nd doubles) over PCIe per iteration.  The P x P
-    bounded Levenberg-Marquardt algebra itself stays batched numpy on the host.  ``device_algebra=False`` is the round-1 path (A/B)."""
+    points.  ``device_algebra=True``: residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU (torch ops on the
+    `flat` tensors the kernel wrote); per iteration and row only P x P + P doubles come back and a P-vector of trial parameters goes up.
+    ``False``: round 1's path -- every ``flat`` vector (n_active * P x Nd doubles per iteration) crosses PCIe and numpy does the algebra.
+    ``"auto"`` (default) picks by the size of that transfer (> 2 MB: device).  Measured on MI355X (bench.py `lm_fit`): at 1 MB per Jacobian
+    (48 starts, P = 20) the two paths tie (145-220 ms host, 183-186 ms device per 60-iteration fit: a dozen small torch launches and their
+    synchronisations cost what the copy costs); at 109 MB (480 rows, P = 64: the lambda scan of a 30-site protein) the device path
+    takes 0.39 s against 3.4 s.  The P x P bounded Levenberg-Marquardt algebra itself is batched numpy on the host either way."""
     import torch
     log_space = (model == "randmod")
     P0 = np.atleast_2d(np.asarray(P0, float))
@@ -107,6 +110,8 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     n_solves = 0
     n_launches = 0
     dev = torch.device("cuda", batch.get_context().device)
+    if device_algebra == "auto":
+        device_algebra = R * P * Nd * 8 > (2 << 20)                   # bytes of `flat` one Jacobian evaluation would move over PCIe
     if device_algebra:
         t_d = torch.as_tensor(tfull, device=dev); isig_d = torch.as_tensor(1.0 / sig, device=dev); lam_d = torch.as_tensor(lam / P, device=dev)
         y0_d = torch.as_tensor(np.array(y0, dtype=float, copy=True), device=dev)

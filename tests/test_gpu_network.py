@@ -527,7 +527,7 @@ def test_full_size_network_config5_properties(model):
 
 
 def test_full_size_network_config4_morris():
-    """BASELINE config 4 size: ~25 700 network simulations (30 Morris trajectories x (841 varied parameters + 1)) in one batch -> fold-change
+    """BASELINE config 4 size: 128 Morris trajectories x (841 varied parameters + 1) = 107 776 network simulations in one batch -> fold-change
     observables -> scalar metric -> elementary effects.  Size-independent checks: nothing flagged, every parameter gets a finite mu*,
     the Morris output of the unperturbed centre equals the direct evaluation, and mu* is invariant under a permutation of trajectories."""
     import time
@@ -541,17 +541,17 @@ def test_full_size_network_config4_morris():
                   Dp_i=x0[nK + 4 * N:nK + 4 * N + sites], E_i=x0[nK + 4 * N + sites:nK + 5 * N + sites], tf_scale=float(x0[-1]))
     tp = net["kin_grid"]; tr = np.array([4.0, 8.0, 15.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
     t0 = time.perf_counter()
-    out = gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, perturbation=0.05, trajectories=30, num_levels=40, seed=3)
+    out = gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, perturbation=0.05, trajectories=128, num_levels=40, seed=3)      # BASELINE config 4: 128 trajectories
     wall = time.perf_counter() - t0
     B = out["param_values"].shape[0]
-    assert B == 30 * (eng.n_var + 1) and not out["status"].any() and np.isfinite(out["Y"]).all()
+    assert B == 128 * (eng.n_var + 1) and not out["status"].any() and np.isfinite(out["Y"]).all()
     Si = out["Si"]
     assert np.isfinite(Si["mu_star"]).all() and (Si["mu_star"] >= 0).all() and Si["mu_star"].max() > 0
     # permuting whole trajectories changes nothing in mu / mu_star
     D = eng.n_var
-    perm = np.random.default_rng(0).permutation(30)
-    Xp = out["param_values"].reshape(30, D + 1, D)[perm].reshape(-1, D)
-    Yp = out["Y"].reshape(30, D + 1)[perm].reshape(-1)
+    perm = np.random.default_rng(0).permutation(128)
+    Xp = out["param_values"].reshape(128, D + 1, D)[perm].reshape(-1, D)
+    Yp = out["Y"].reshape(128, D + 1)[perm].reshape(-1)
     from phoskintime_amd.sensitivity import morris
     Sp = morris.analyze(out["problem"], Xp, Yp, num_levels=40, num_resamples=0)
     np.testing.assert_allclose(Sp["mu_star"], Si["mu_star"], rtol=1e-12, atol=1e-14)
