@@ -322,6 +322,9 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
       static const double tolfac = [] { const char* v = getenv("PK_ARK_TOLFAC"); const double f = v ? atof(v) : 0.0; return (f > 0.0 && f <= 1.0) ? f : 0.25; }();
       pk::NetSolveArgs aa = a;
       aa.rtol *= tolfac; aa.atol *= tolfac;
+      static const double ctl_s = [] { const char* v = getenv("PK_ARK_SAFETY"); return v ? atof(v) : 0.0; }();      // dev knobs of the controller
+      static const double ctl_g = [] { const char* v = getenv("PK_ARK_GROW"); return v ? atof(v) : 0.0; }();
+      aa.ctl_safety = ctl_s; aa.ctl_grow = ctl_g;
       hipError_t ea = pk::launch_net_ark(n->d, aa, n->max_sites, (long long)B, threads_a, lds_a, stream);
       if (ea == hipSuccess) ea = hipGetLastError();
       return ea == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(ea));

@@ -43,6 +43,7 @@ struct NetSolveArgs {
   double* Y;                       // [B, T, S]
   int32_t* status; int32_t* n_steps;
   double rtol, atol, h0; int max_steps;
+  double ctl_safety, ctl_grow;     // step-size controller of the additive kernels: h_new = h * min(ctl_grow, ctl_safety / err^(1/4)) (0: defaults 0.9, 6)
   int err_rms;                     // 1: ODEPACK's weighted root-mean-square error norm (what the reference's LSODA controls); 0: max norm
 };
 

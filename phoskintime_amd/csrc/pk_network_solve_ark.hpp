@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark_kernel(const NetDev n, c
     if (!(h > 0.0) || h != h) h = 1e-6;
   }
   const bool rms = A.err_rms;
+  const double safety_inv = 1.0 / (A.ctl_safety > 0.0 ? A.ctl_safety : 0.9), grow_inv = 1.0 / (A.ctl_grow > 1.0 ? A.ctl_grow : 6.0);
   bool after_reject = false;
   for (int si = 0; si < A.n_stops && status == PK_ST_OK; ++si) {
     const double te = stops[si];
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark_kernel(const NetDev n, c
         if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
         continue;
       }
-      double fac = sqrt(sqrt(err)) * (1.0 / 0.9);                            // embedded order 3: err^(1/4)
-      fac = fmax(1.0 / 6.0, fmin(5.0, fac));
+      double fac = sqrt(sqrt(err)) * safety_inv;                             // embedded order 3: err^(1/4)
+      fac = fmax(grow_inv, fmin(5.0, fac));
       double hnew = hs * net_rcp(fac);
       if (err <= 1.0) {
         ++nacc;
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark2_kernel(const NetDev n, 
     if (!(h > 0.0) || h != h) h = 1e-6;
   }
   const bool rms = A.err_rms;
+  const double safety_inv = 1.0 / (A.ctl_safety > 0.0 ? A.ctl_safety : 0.9), grow_inv = 1.0 / (A.ctl_grow > 1.0 ? A.ctl_grow : 6.0);
   bool after_reject = false;
   for (int si = 0; si < A.n_stops && status == PK_ST_OK; ++si) {
     const double te = stops[si];
@@ -590,8 +592,8 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark2_kernel(const NetDev n, 
         if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
         continue;
       }
-      double fac = sqrt(sqrt(err)) * (1.0 / 0.9);
-      fac = fmax(1.0 / 6.0, fmin(5.0, fac));
+      double fac = sqrt(sqrt(err)) * safety_inv;
+      fac = fmax(grow_inv, fmin(5.0, fac));
       double hnew = hs * net_rcp(fac);
       if (err <= 1.0) {
         ++nacc;
