@@ -2,6 +2,7 @@
 #include "pk_wide.hpp"
 #include "pk_launch.hpp"
 #include <atomic>
+#include <cstdlib>
 
 namespace pk {
 
@@ -43,22 +44,28 @@ hipError_t launch_wide_chain(const SolveArgs& a, int model, hipStream_t st) {
 }
 
 // scratch == nullptr: the vectors live in LDS (caller checked wide_rand_in_lds); else one row of `stride` doubles per replica in HBM
-bool wide_rand_in_lds(int n) { return n <= 16 && wide_rand_lds_bytes(n, true) <= kLdsMax; }
-size_t wide_rand_scratch_bytes(int n, long long B) { return wide_rand_in_lds(n) ? 0 : (size_t)B * wide_rand_scratch_doubles(n) * sizeof(double); }
+// the order-4 additive method is the default (PK_WIDE_RAND_ROSW=1, read once, selects round-2's first version: ROS34PW2-W)
+static bool wide_rand_ark() { static const bool rosw = [] { const char* v = getenv("PK_WIDE_RAND_ROSW"); return v && atoi(v) == 1; }(); return !rosw; }
+bool wide_rand_in_lds(int n) { return n <= 16 && wide_rand_lds_bytes(n, true, wide_rand_ark()) <= kLdsMax; }
+size_t wide_rand_scratch_bytes(int n, long long B) { return wide_rand_in_lds(n) ? 0 : (size_t)B * wide_rand_scratch_doubles(n, wide_rand_ark()) * sizeof(double); }
 
-hipError_t launch_wide_rand(const SolveArgs& a, double* scratch, hipStream_t st) {
+template <bool ARK>
+static hipError_t launch_wide_rand_m(const SolveArgs& a, double* scratch, hipStream_t st) {
   const int n = a.n_sites;
   const int NM = 1 << n;
   const int nt = NM <= 128 ? 64 : NM <= 256 ? 128 : 256;
   hipError_t e;
   if (!scratch) {
     static std::atomic<uint64_t> ready{0};
-    if ((e = allow_lds(wide_rand_kernel<true>, ready)) != hipSuccess) return e;
-    hipLaunchKernelGGL((wide_rand_kernel<true>), dim3((unsigned)a.B), dim3(nt), wide_rand_lds_bytes(n, true), st, a, (double*)nullptr, (size_t)0);
+    if ((e = allow_lds(wide_rand_kernel<true, ARK>, ready)) != hipSuccess) return e;
+    hipLaunchKernelGGL((wide_rand_kernel<true, ARK>), dim3((unsigned)a.B), dim3(nt), wide_rand_lds_bytes(n, true, ARK), st, a, (double*)nullptr, (size_t)0);
   } else {
-    hipLaunchKernelGGL((wide_rand_kernel<false>), dim3((unsigned)a.B), dim3(256), wide_rand_lds_bytes(n, false), st, a, scratch, wide_rand_scratch_doubles(n));
+    hipLaunchKernelGGL((wide_rand_kernel<false, ARK>), dim3((unsigned)a.B), dim3(256), wide_rand_lds_bytes(n, false, ARK), st, a, scratch, wide_rand_scratch_doubles(n, ARK));
   }
   return hipSuccess;
+}
+hipError_t launch_wide_rand(const SolveArgs& a, double* scratch, hipStream_t st) {
+  return wide_rand_ark() ? launch_wide_rand_m<true>(a, scratch, st) : launch_wide_rand_m<false>(a, scratch, st);
 }
 
 // steady state beyond 64 states; returns hipErrorInvalidValue when the system does not fit LDS (randmod n_sites >= 13)
