@@ -402,7 +402,7 @@ def lm_leg():
     from phoskintime_amd import batch
     from phoskintime_amd.paramest import fit_rows_batch, multistart_candidates
     out = {}
-    for label, n, rows, iters in (("multistart_48_starts_distmod_n8", 8, 48, 60), ("lambda_scan_480_rows_distmod_n30", 30, 480, 12)):
+    for label, n, rows, iters in (("multistart_48_starts_distmod_n8", 8, 48, 60), ("rows_480_distmod_n8", 8, 480, 60), ("lambda_scan_480_rows_distmod_n30", 30, 480, 12)):
         P, S = 4 + 2 * n, n + 2
         rng = np.random.default_rng(20260515 + 9)
         th_true = rng.uniform(0.2, 2.0, P)
@@ -411,17 +411,21 @@ def lm_leg():
         lb, ub = np.zeros(P), np.full(P, 20.0)
         P0 = multistart_candidates("BENCH", rng.uniform(lb, ub), lb, ub, n_starts=rows)
         leg = {"rows": rows, "P": P, "residuals": int(flat.size), "flat_bytes_per_jacobian": rows * P * flat.size * 8}
-        for name, dev_alg in (("device_algebra", True), ("host_algebra_round1", False)):
-            fit_rows_batch("distmod", n, TGRID, P0[:4], np.ones(S), target, bounds=(lb, ub), max_iter=2, device_algebra=dev_alg)
+        modes = [("device_algebra", True, "fd"), ("host_algebra_round1", False, "fd")]
+        if batch.sens_available("distmod", n):
+            modes.insert(0, ("forward_sensitivities", "auto", "sens"))
+        for name, dev_alg, jac in modes:
+            fit_rows_batch("distmod", n, TGRID, P0[:4], np.ones(S), target, bounds=(lb, ub), max_iter=2, device_algebra=dev_alg, jacobian=jac)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            fit = fit_rows_batch("distmod", n, TGRID, P0, np.ones(S), target, bounds=(lb, ub), max_iter=iters, device_algebra=dev_alg)
+            fit = fit_rows_batch("distmod", n, TGRID, P0, np.ones(S), target, bounds=(lb, ub), max_iter=iters, device_algebra=dev_alg, jacobian=jac)
             torch.cuda.synchronize()
             leg[name] = {"wall_ms": 1e3 * (time.perf_counter() - t1), "iterations": fit.n_iter, "solves": fit.n_solves, "launches": fit.n_launches,
-                         "best_cost": float(fit.cost.min())}
-        leg["auto_picks"] = "device" if rows * P * flat.size * 8 > (2 << 20) else "host"
+                         "best_cost": float(fit.cost.min()), "median_cost": float(np.median(fit.cost))}
+        leg["auto_picks"] = ("forward_sensitivities" if batch.sens_available("distmod", n) else "device_algebra" if rows * P * flat.size * 8 > (2 << 20) else "host_algebra_round1")
         out[label] = leg
-    out["workload"] = "bounded LM fits of models.distmod (2 % noise on the target), forward-difference Jacobian columns on the throughput kernels"
+    out["workload"] = ("bounded LM fits of models.distmod (2 % noise on the target); forward_sensitivities: one launch of the sensitivity kernel per Jacobian "
+                       "(n_active integrations with their P tangents); the other two: forward-difference columns (n_active * P replicas) on the throughput kernels")
     return out
 
 

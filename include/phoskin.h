@@ -142,6 +142,20 @@ int pk_solve_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
                            double* sol, double* flat, double* metric, int metric_id,
                            int32_t* status, int32_t* n_steps);
 
+/* flat(theta) AND its parameter Jacobian d flat / d theta from ONE integration (forward sensitivities: S' = J S + df/dtheta solved with the
+ * factors of the state solve, differentiated stage by stage: csrc/pk_sens.hpp).  Replaces the 1 + P calls of models.solve_ode per Jacobian
+ * that scipy.optimize.curve_fit's '2-point' differences make under paramest/normest.py:167-326 and paramest/toggle.py.
+ *   flat [B,F]; dflat [B,F,P] (row-major: the P derivatives of one flat entry are contiguous); status / n_steps as above.
+ * The derivative follows flat's own post-processing: 0 where the value was clipped at 0, scaled by 1 / y0 under opts->normalize.
+ * Tangents are held to the same rtol / atol as the states (maximum norm over all columns).  Method LRP12 only.
+ * Sizes: pk_protein_sens_available(model, n_sites) != 0 -- distmod / succmod n_sites <= 14, randmod n_sites <= 3; PK_ERR_UNSUPPORTED beyond
+ * (callers difference pk_solve_protein_batch there, as phoskintime_amd.paramest.fit_rows_batch does). */
+int pk_protein_sens_available(int model, int n_sites);
+int pk_solve_protein_sens_batch(pk_ctx*, int model, int n_sites, int64_t B,
+                                const double* theta, const double* y0, int y0_is_batched,
+                                const double* t, int T, const pk_solver_opts* opts,
+                                double* flat, double* dflat, int32_t* status, int32_t* n_steps);
+
 /* Replaces models.{distmod,succmod}.ode_core / models.randmod.ode_system (distmod.py:7-65, succmod.py:9-90,
  * randmod.py:122-247) evaluated for a batch: y [B,S] -> dydt [B,S]. */
 int pk_rhs_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,

@@ -156,6 +156,58 @@ def solve_ode_batch(model, theta: ArrayLike, init_cond: ArrayLike, num_psites: i
     return out
 
 
+def sens_available(model, num_psites: int) -> bool:
+    """True where ``solve_ode_sens_batch`` has a kernel (distmod / succmod n <= 14, randmod n <= 3).  Pure host arithmetic."""
+    return bool(_capi.load().pk_protein_sens_available(model_id(model), int(num_psites)))
+
+
+@dataclass
+class SensResult:
+    flat: torch.Tensor                # [B, F]
+    dflat: torch.Tensor               # [B, F, P]  d flat / d theta
+    status: torch.Tensor              # [B] int32
+    n_steps: torch.Tensor             # [B, 2] int32
+
+
+def solve_ode_sens_batch(model, theta: ArrayLike, init_cond: ArrayLike, num_psites: int, t: ArrayLike, *,
+                         rtol: Optional[float] = None, atol: Optional[float] = None, h0: Optional[float] = None, max_steps: Optional[int] = None,
+                         clip_nonneg: bool = True, normalize: bool = False, device: Optional[int] = None) -> SensResult:
+    """``flat`` of the reference's ``solve_ode`` AND its Jacobian d flat / d theta for B parameter vectors from one launch (forward
+    sensitivities, csrc/pk_sens.hpp) -- what scipy's curve_fit obtains from 1 + P calls of ``solve_ode`` (paramest/normest.py:167-326).
+    Raises ``PhoskinError`` (PK_ERR_UNSUPPORTED) for sizes without a kernel: see ``sens_available``."""
+    ctx = get_context(device)
+    dev = torch.device("cuda", ctx.device)
+    mid = model_id(model)
+    n = int(num_psites)
+    S, P = n_states(mid, n), n_params(mid, n)
+    th = _dev_f64(theta, dev)
+    if th.dim() == 1:
+        th = th.unsqueeze(0)
+    if th.dim() != 2 or th.shape[1] != P:
+        raise ValueError(f"theta must be [B, {P}] for model {mid} with {n} sites, got {tuple(th.shape)}")
+    B = th.shape[0]
+    y0 = _dev_f64(init_cond, dev)
+    if y0.shape == (S,):
+        batched = 0
+    elif y0.shape == (B, S):
+        batched = 1
+    else:
+        raise ValueError(f"init_cond must be [{S}] or [{B}, {S}], got {tuple(y0.shape)}")
+    tt = _dev_f64(np.atleast_1d(t) if not isinstance(t, torch.Tensor) else t, dev).reshape(-1)
+    T = tt.numel()
+    if T < 1:
+        raise ValueError("t must hold at least one time point")
+    F = flat_len(mid, n, T)
+    opts = default_opts(rtol=rtol, atol=atol, h0=h0, max_steps=max_steps, clip_nonneg=int(bool(clip_nonneg)), normalize=int(bool(normalize)))
+    out = SensResult(flat=torch.empty((B, F), dtype=torch.float64, device=dev), dflat=torch.empty((B, F, P), dtype=torch.float64, device=dev),
+                     status=torch.zeros((B,), dtype=torch.int32, device=dev), n_steps=torch.zeros((B, 2), dtype=torch.int32, device=dev))
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.check(ctx.lib.pk_solve_protein_sens_batch(ctx.handle, mid, n, B, _ptr(th), _ptr(y0), batched, _ptr(tt), T, C.byref(opts),
+                                                  _ptr(out.flat), _ptr(out.dflat), _ptr(out.status), _ptr(out.n_steps)))
+    out._keepalive = (th, y0, tt)  # type: ignore[attr-defined]
+    return out
+
+
 def rhs_batch(model, theta: ArrayLike, y: ArrayLike, num_psites: int, device: Optional[int] = None) -> torch.Tensor:
     """dy/dt for B (theta, y) pairs: reference ``ode_core`` / ``ode_system`` batched.  Returns [B, S] on the GPU."""
     ctx = get_context(device)

@@ -8,6 +8,7 @@
 #include <string>
 #include "../../include/phoskin.h"
 #include "pk_launch.hpp"
+#include "pk_sens.hpp"
 
 // A growable device buffer that outlives calls: the `_host` entry points stage through one, kernels that need per-replica HBM scratch
 // use another (two, so that an inner device-pointer call can never move the staging area of the `_host` call around it).
@@ -368,6 +369,41 @@ struct HostCall {
 };
 }  // namespace
 extern "C" {
+
+int pk_protein_sens_available(int model, int n_sites) {
+  if (model < 0 || model > 2 || n_sites < 1) return 0;
+  return pk::sens_available(model, n_sites) ? 1 : 0;
+}
+
+int pk_solve_protein_sens_batch(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y0, int y0_is_batched,
+                                const double* t, int T, const pk_solver_opts* opts_in, double* flat, double* dflat, int32_t* status,
+                                int32_t* n_steps) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
+  if (T < 1) return fail(c, PK_ERR_ARG, "T must be >= 1");
+  if (!pk::sens_available(model, n_sites))
+    return fail(c, PK_ERR_UNSUPPORTED, "forward sensitivities: distmod / succmod n_sites <= 14, randmod n_sites <= 3 (difference the batched solve beyond)");
+  if (B == 0) return PK_OK;
+  if (!theta || !y0 || !t || !flat || !dflat) return fail(c, PK_ERR_ARG, "theta, y0, t, flat and dflat must be non-null");
+  pk_solver_opts o;
+  if (opts_in) o = *opts_in; else pk_default_opts(&o);
+  if (o.method != PK_METHOD_LRP12 || o.stage_form) return fail(c, PK_ERR_UNSUPPORTED, "forward sensitivities integrate with method LRP12 (the default) only");
+  if (!(o.rtol > 0.0 && o.atol >= 0.0)) return fail(c, PK_ERR_ARG, "rtol must be > 0 and atol >= 0");
+  if (o.max_steps <= 0) o.max_steps = 100000;
+  pk::SensArgs sa;
+  pk::SolveArgs& a = sa.s;
+  a.theta = theta; a.y0 = y0; a.t = t; a.sol = nullptr; a.flat = flat; a.metric = nullptr; a.status = status; a.n_steps = n_steps;
+  a.B = B; a.n_sites = n_sites; a.S = pk::n_states(model, n_sites); a.P = pk::n_params(model, n_sites); a.T = T;
+  a.F = pk_protein_flat_len(model, n_sites, T); a.n_obs = n_sites; a.y0_batched = y0_is_batched ? 1 : 0; a.metric_id = 0;
+  a.rtol = o.rtol; a.atol = o.atol; a.h0 = o.h0; a.rk4_h = o.rk4_h; a.max_steps = o.max_steps; a.clip = o.clip_nonneg; a.normalize = o.normalize; a.stage_form = 0;
+  sa.dflat = dflat;
+  if (B > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, pk::launch_sens(sa, model, c->stream));
+  return PK_OK;
+}
 
 int pk_solve_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y0,
                                 int y0_is_batched, const double* t, int T, const pk_solver_opts* opts, double* sol,

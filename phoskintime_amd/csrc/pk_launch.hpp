@@ -27,6 +27,10 @@ void launch_rand_fast(const SolveArgs&, int method, hipStream_t);
 // thread-per-replica kernels for small distributive / successive systems (pk_tpr.hpp), LRP12
 bool tpr_available(int model, int n_sites);
 hipError_t launch_tpr(const SolveArgs&, int model, hipStream_t);   // sets the dynamic-LDS limit per device; its error is the caller's
+// forward parameter sensitivities, one column per lane (pk_sens.hpp), LRP12
+struct SensArgs;
+bool sens_available(int model, int n_sites);
+hipError_t launch_sens(const SensArgs&, int model, hipStream_t);
 // workgroup-per-replica kernels for systems beyond 64 rows (pk_wide.hpp)
 bool wide_chain_fits(int S, int n_sites);                                   // distmod / succmod: 15 LDS vectors of S doubles
 hipError_t launch_wide_chain(const SolveArgs&, int model, hipStream_t);     // LRP12, exact solves

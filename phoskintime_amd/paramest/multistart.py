@@ -70,7 +70,7 @@ class RowsFit:
 
 
 def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None,
-                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra="auto", **solver_kw) -> RowsFit:
+                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra="auto", jacobian="auto", **solver_kw) -> RowsFit:
     """R independent bounded least-squares problems in lockstep: row k fits ``[flat(p) ; lam_k / P * p**2]`` to ``[target_k ; 0]`` with
     weights ``sigma_k`` from the start point ``P0[k]``.  Rows may be the starts of one multistart fit, the (lambda, weight) grid of
     ``find_best_lambda``, bootstrap replicates, different proteins of the same size -- or any mix.
@@ -78,8 +78,12 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     P0 [R, P]; init_cond [S] or [R, S]; target [Nd] or [R, Nd]; sigma None, [Nr] or [R, Nr] with Nr = Nd (+ P when any lam > 0);
     lam scalar or [R]; bounds (lb, ub), each [P] or [R, P].
 
-    Every iteration is ONE launch for the Jacobian columns (n_active * P replicas) plus one launch per damping round for the trial
-    points.  ``device_algebra=True``: residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU (torch ops on the
+    ``jacobian="sens"``: the Jacobian of every active row comes from ONE launch of the forward-sensitivity kernel (csrc/pk_sens.hpp:
+    n_active integrations, each carrying its P tangents; exact derivative of the discrete solution) -- ``"fd"``: SciPy's '2-point'
+    forward differences, one launch of n_active * P perturbed replicas on the throughput kernels, which is what the reference's
+    curve_fit does call by call.  ``"auto"`` (default) takes "sens" where a kernel exists (``batch.sens_available``: distmod / succmod
+    n <= 14, randmod n <= 3) and the solver options are the default method's, else "fd".  Either way one more launch per damping round
+    evaluates the trial points.  ``device_algebra=True``: residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU (torch ops on the
     `flat` tensors the kernel wrote); per iteration and row only P x P + P doubles come back and a P-vector of trial parameters goes up.
     ``False``: round 1's path -- every ``flat`` vector (n_active * P x Nd doubles per iteration) crosses PCIe and numpy does the algebra.
     ``"auto"`` (default) picks by the size of that transfer (> 2 MB: device).  Measured on MI355X (bench.py `lm_fit`): at 1 MB per Jacobian
@@ -126,6 +130,31 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         rr = (f - t_d[rows_d]) * isig_d[rows_d]
         return torch.where(torch.isfinite(rr), rr, torch.full_like(rr, 1e6))            # failed solves are very bad, not fatal
 
+    sens_kw = {k: v for k, v in solver_kw.items() if k in ("rtol", "atol", "h0", "max_steps", "clip_nonneg", "normalize")}
+    sens_ok = batch.sens_available(model, num_psites) and all(k in sens_kw or v is None or (k == "method" and v in ("lrp12", 5)) or k == "kernel"
+                                                               for k, v in solver_kw.items())
+    if jacobian == "auto":
+        jacobian = "sens" if sens_ok else "fd"
+    if jacobian not in ("sens", "fd"):
+        raise ValueError("jacobian must be 'auto', 'sens' or 'fd'")
+    if jacobian == "sens" and not sens_ok:
+        raise ValueError("jacobian='sens': no sensitivity kernel for this model size / these solver options (batch.sens_available)")
+
+    def jacobian_sens(Pm, rows):
+        """d (weighted residuals) / d p for the problems `rows` at Pm [m, P] from one sensitivity launch -> [m, Nr, P] (GPU tensor)."""
+        nonlocal n_solves, n_launches
+        Pm_d = torch.as_tensor(Pm, device=dev)
+        theta = torch.exp(Pm_d) if log_space else Pm_d
+        y0s = (y0_d[torch.as_tensor(rows, device=dev)] if y0_rows else y0_d) if device_algebra else (y0[rows] if y0_rows else y0)
+        res = batch.solve_ode_sens_batch(model, theta, y0s, num_psites, time_points, **sens_kw)
+        n_solves += Pm_d.shape[0]; n_launches += 1
+        D = res.dflat * theta[:, None, :] if log_space else res.dflat                   # chain rule of theta = exp(p)
+        if use_reg:
+            lam_rows = torch.as_tensor(lam[rows] / P, device=dev)
+            D = torch.cat([D, torch.diag_embed(2.0 * lam_rows[:, None] * Pm_d)], dim=1)
+        D = D * torch.as_tensor(1.0 / sig[rows], device=dev)[:, :, None]
+        return torch.where(torch.isfinite(D), D, torch.zeros_like(D))                   # a failed solve contributes no direction
+
     def residuals(Pm, rows):
         """Host path: Pm [m, P] for the problems `rows` [m] -> weighted residuals [m, Nr]  (one launch, flat over PCIe)."""
         nonlocal n_solves, n_launches
@@ -156,9 +185,18 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         # forward-difference Jacobian (SciPy's '2-point' rule: h = sqrt(eps) * max(1, |p|), flipped at the upper bound)
         h = np.sqrt(np.finfo(float).eps) * np.maximum(1.0, np.abs(p[idx]))
         h = np.where(p[idx] + h > ub[idx], -h, h)
-        Pp = np.repeat(p[idx], P, axis=0)
-        Pp[np.arange(idx.size * P), np.tile(np.arange(P), idx.size)] += h.reshape(-1)
-        if device_algebra:
+        if jacobian == "fd":
+            Pp = np.repeat(p[idx], P, axis=0)
+            Pp[np.arange(idx.size * P), np.tile(np.arange(P), idx.size)] += h.reshape(-1)
+        if jacobian == "sens":
+            Jd = jacobian_sens(p[idx], idx)                                                                          # [k, Nr, P]
+            if device_algebra:
+                r_at = r_d[torch.as_tensor(idx, device=dev)]
+            else:
+                r_at = torch.as_tensor(r[idx], device=dev)
+            A = torch.bmm(Jd.transpose(1, 2), Jd).cpu().numpy()
+            g = torch.bmm(Jd.transpose(1, 2), r_at[:, :, None])[:, :, 0].cpu().numpy()
+        elif device_algebra:
             idx_d = torch.as_tensor(idx, device=dev)
             rp = residuals_dev(torch.as_tensor(Pp, device=dev), idx_d.repeat_interleave(P)).reshape(idx.size, P, Nr)
             Jd = ((rp - r_d[idx_d][:, None, :]) / torch.as_tensor(h, device=dev)[:, :, None]).transpose(1, 2)        # [k, Nr, P]

@@ -1,0 +1,130 @@
+"""GPU: forward parameter sensitivities (csrc/pk_sens.hpp, pk_solve_protein_sens_batch) against central differences of the oracle's
+integrator-free solution (oracle.protein_models.solve_exact_lti: matrix exponentials), and the Levenberg-Marquardt driver on them.
+Reference behaviour replaced: scipy.optimize.curve_fit's '2-point' differencing of models.solve_ode (paramest/normest.py:167-326)."""
+import numpy as np
+import pytest
+
+from oracle import protein_models as pm
+
+pytestmark = pytest.mark.gpu
+
+SENS_RTOL = 1e-7          # d flat / d theta against the oracle's central differences: |diff| <= SENS_RTOL * (1 + |d|)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from phoskintime_amd import batch
+    batch.get_context()
+    return batch
+
+
+def _oracle_flat(model, th, y0, n, t):
+    sol = pm.solve_exact_lti(model, th, y0, n, t)
+    return pm.flatten_observables(model, np.clip(sol, 0.0, None), n)
+
+
+def _oracle_jac(model, th, y0, n, t):
+    P = th.size
+    cols = []
+    for c in range(P):
+        h = 1e-5 * max(1.0, abs(th[c]))
+        tp, tm = th.copy(), th.copy()
+        tp[c] += h; tm[c] -= h
+        cols.append((_oracle_flat(model, tp, y0, n, t) - _oracle_flat(model, tm, y0, n, t)) / (2 * h))
+    return np.stack(cols, axis=1)                      # [F, P]
+
+
+CASES = [("distmod", 1), ("distmod", 3), ("distmod", 4), ("distmod", 8), ("distmod", 13), ("distmod", 14),
+         ("succmod", 1), ("succmod", 2), ("succmod", 5), ("succmod", 9), ("succmod", 14),
+         ("randmod", 1), ("randmod", 2), ("randmod", 3)]
+
+
+@pytest.mark.parametrize("model,n", CASES)
+def test_sensitivities_match_central_differences_of_the_oracle(eng, model, n):
+    mid = pm.MODEL_IDS[model]
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    rng = np.random.default_rng(100 * mid + n)
+    B = 5                                               # not a multiple of the replicas per wave: the last wave carries shadow groups
+    th = rng.uniform(0.2, 2.0, size=(B, P))
+    y0 = rng.uniform(0.3, 1.5, size=S)
+    t = pm.TIME_POINTS
+    res = eng.solve_ode_sens_batch(model, th, y0, n, t, rtol=1e-9, atol=1e-11)
+    assert int(res.status.cpu().numpy().max()) == 0
+    flat = res.flat.cpu().numpy(); dflat = res.dflat.cpu().numpy()
+    plain = eng.solve_ode_batch(model, th, y0, n, t, want_sol=False, rtol=1e-9, atol=1e-11).flat.cpu().numpy()
+    assert np.max(np.abs(flat - plain) / (1e-8 + 1e-6 * np.abs(plain))) < 0.1
+    for b in (0, B - 1):
+        ref_f = _oracle_flat(mid, th[b], y0, n, t)
+        assert pm.band_error(flat[b], ref_f) < 0.1
+        ref_J = _oracle_jac(mid, th[b], y0, n, t)
+        err = np.abs(dflat[b] - ref_J) / (1.0 + np.abs(ref_J))
+        assert err.max() < SENS_RTOL, (model, n, b, err.max())
+        assert np.all(dflat[b][flat[b] == y0[0] if False else np.zeros_like(flat[b], bool)] == 0.0)
+
+
+def test_sensitivities_follow_flat_postprocessing_and_batched_y0(eng):
+    rng = np.random.default_rng(7)
+    n, mid = 3, 0
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    B = 9
+    th = rng.uniform(0.2, 2.0, size=(B, P)); y0 = rng.uniform(0.5, 2.0, size=(B, S))
+    t = pm.TIME_POINTS
+    a = eng.solve_ode_sens_batch("distmod", th, y0, n, t, normalize=False)
+    b = eng.solve_ode_sens_batch("distmod", th, y0, n, t, normalize=True)
+    T = t.size
+    # flat = [R(t5..), P(t0..), sites site-major]: the scale of every entry is 1 / y0 of its state
+    scale = np.concatenate([np.repeat(y0[:, :1], T - 5, axis=1), np.repeat(y0[:, 1:2], T, axis=1)] + [np.repeat(y0[:, 2 + j:3 + j], T, axis=1) for j in range(n)], axis=1)
+    np.testing.assert_allclose(b.flat.cpu().numpy() * scale, a.flat.cpu().numpy(), rtol=1e-12, atol=0)
+    np.testing.assert_allclose(b.dflat.cpu().numpy() * scale[:, :, None], a.dflat.cpu().numpy(), rtol=1e-10, atol=1e-14)
+    # the entries at t0 are data: zero derivative
+    d = a.dflat.cpu().numpy()
+    assert np.all(d[:, T - 5, :] == 0.0)                # P(t0)
+    # replica independence: a row computed alone gives the same bits
+    one = eng.solve_ode_sens_batch("distmod", th[4:5], y0[4:5], n, t)
+    assert np.array_equal(one.dflat.cpu().numpy()[0], d[4])
+
+
+def test_sizes_without_a_sensitivity_kernel_are_refused(eng):
+    from phoskintime_amd._capi import PhoskinError
+    assert eng.sens_available("distmod", 14) and not eng.sens_available("distmod", 15)
+    assert eng.sens_available("randmod", 3) and not eng.sens_available("randmod", 4)
+    with pytest.raises(PhoskinError):
+        eng.solve_ode_sens_batch("randmod", np.ones((1, pm.n_params(2, 4))), np.ones(pm.n_states(2, 4)), 4, pm.TIME_POINTS)
+    with pytest.raises(PhoskinError):
+        eng.solve_ode_sens_batch("distmod", np.ones((1, pm.n_params(0, 20))), np.ones(22), 20, pm.TIME_POINTS)
+    # failed replicas: flagged, NaN rows, the rest of the batch unaffected
+    th = np.ones((3, 10)); th[1, 1] = np.nan
+    r = eng.solve_ode_sens_batch("distmod", th, np.ones(5), 3, pm.TIME_POINTS)
+    st = r.status.cpu().numpy()
+    assert st[0] == 0 and st[2] == 0 and st[1] != 0
+    assert np.isnan(r.dflat.cpu().numpy()[1, -1]).all() and np.isfinite(r.dflat.cpu().numpy()[[0, 2]]).all()
+
+
+@pytest.mark.parametrize("model,n", [("distmod", 4), ("succmod", 3), ("randmod", 2)])
+def test_levenberg_marquardt_on_sensitivities_matches_the_differenced_fit(eng, model, n):
+    from phoskintime_amd.paramest import multistart as ms
+    mid = pm.MODEL_IDS[model]
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    rng = np.random.default_rng(11)
+    truth = rng.uniform(0.5, 1.5, size=P)
+    y0 = np.ones(S)
+    t = pm.TIME_POINTS
+    target = eng.solve_ode_batch(model, truth[None], y0, n, t, want_sol=False).flat.cpu().numpy()[0]
+    R = 12
+    log = model == "randmod"
+    P0 = truth * rng.uniform(0.7, 1.4, size=(R, P))
+    lb, ub = np.full(P, 1e-3), np.full(P, 10.0)
+    if log:
+        P0, lb, ub = np.log(P0), np.log(lb), np.log(ub)
+    fits = {}
+    for jac in ("sens", "fd"):
+        fits[jac] = ms.fit_rows_batch(model, n, t, P0, y0, target, bounds=(lb, ub), jacobian=jac, max_iter=200)
+    s, f = fits["sens"], fits["fd"]
+    # one Jacobian launch per iteration carries n_active integrations instead of n_active * P
+    assert s.n_solves < f.n_solves / 2
+    pred = lambda fit: eng.solve_ode_batch(model, np.exp(fit.p) if log else fit.p, y0, n, t, want_sol=False).flat.cpu().numpy()
+    # both reach the data (the parameters themselves are only weakly identified: compare in data space)
+    assert np.median(np.abs(pred(s) - target).max(axis=1)) < 1e-5
+    assert np.median(s.cost) <= 10.0 * np.median(f.cost) + 1e-12

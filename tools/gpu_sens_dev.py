@@ -1,0 +1,38 @@
+"""Dev tool: timing of the forward-sensitivity kernel against the differenced batch solve, and of fit_rows_batch on both."""
+import sys, time, pathlib
+import numpy as np, torch
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+from phoskintime_amd import batch
+from phoskintime_amd.paramest import multistart as ms
+from oracle import protein_models as pm
+
+def main():
+    t = pm.TIME_POINTS
+    for model, n in (("distmod", 4), ("distmod", 8), ("distmod", 14), ("succmod", 4), ("succmod", 14), ("randmod", 2), ("randmod", 3)):
+        mid = pm.MODEL_IDS[model]; S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+        rng = np.random.default_rng(1)
+        for B in (64, 4096, 65536):
+            th = torch.as_tensor(rng.uniform(0.2, 2.0, size=(B, P)), device="cuda"); y0 = np.ones(S)
+            batch.solve_ode_sens_batch(model, th[:8], y0, n, t); torch.cuda.synchronize()
+            t0 = time.perf_counter(); r = batch.solve_ode_sens_batch(model, th, y0, n, t); torch.cuda.synchronize(); ts = time.perf_counter() - t0
+            # the differenced Jacobian: B * (1 + P) replicas on the throughput kernels
+            thp = th.repeat_interleave(P + 1, dim=0)
+            batch.solve_ode_batch(model, thp[:8], y0, n, t, want_sol=False); torch.cuda.synchronize()
+            t0 = time.perf_counter(); q = batch.solve_ode_batch(model, thp, y0, n, t, want_sol=False); torch.cuda.synchronize(); tf = time.perf_counter() - t0
+            ns = r.n_steps.cpu().numpy(); nq = q.n_steps.cpu().numpy()
+            print("%s n=%d P=%d B=%d: sens %.2f ms (steps %.0f)   differenced %.2f ms (steps %.0f)   ratio %.2f" % (
+                model, n, P, B, ts * 1e3, ns[:, 0].mean(), tf * 1e3, nq[:, 0].mean(), tf / ts), flush=True)
+    # the LM driver
+    for model, n, R in (("distmod", 4, 48), ("distmod", 8, 480), ("randmod", 3, 48), ("succmod", 14, 96)):
+        mid = pm.MODEL_IDS[model]; S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+        rng = np.random.default_rng(3)
+        truth = rng.uniform(0.5, 1.5, size=P); y0 = np.ones(S)
+        target = batch.solve_ode_batch(model, truth[None], y0, n, t, want_sol=False).flat.cpu().numpy()[0]
+        P0 = truth * rng.uniform(0.7, 1.4, size=(R, P)); lb, ub = np.full(P, 1e-3), np.full(P, 10.0)
+        if model == "randmod": P0, lb, ub = np.log(P0), np.log(lb), np.log(ub)
+        for jac in ("fd", "sens", "fd", "sens"):
+            t0 = time.perf_counter(); f = ms.fit_rows_batch(model, n, t, P0, y0, target, bounds=(lb, ub), jacobian=jac, max_iter=60); dt = time.perf_counter() - t0
+            print("fit %s n=%d R=%d jac=%s: %.1f ms  iters %d solves %d launches %d  median cost %.3e" % (model, n, R, jac, dt * 1e3, f.n_iter, f.n_solves, f.n_launches, np.median(f.cost)), flush=True)
+
+if __name__ == "__main__":
+    main()
