@@ -148,7 +148,7 @@ int pk_solve_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
  *   flat [B,F]; dflat [B,F,P] (row-major: the P derivatives of one flat entry are contiguous); status / n_steps as above.
  * The derivative follows flat's own post-processing: 0 where the value was clipped at 0, scaled by 1 / y0 under opts->normalize.
  * Tangents are held to the same rtol / atol as the states (maximum norm over all columns).  Method LRP12 only.
- * Sizes: pk_protein_sens_available(model, n_sites) != 0 -- distmod / succmod n_sites <= 14, randmod n_sites <= 3; PK_ERR_UNSUPPORTED beyond
+ * Sizes: pk_protein_sens_available(model, n_sites) != 0 -- distmod / succmod n_sites <= 14, randmod n_sites <= 5; PK_ERR_UNSUPPORTED beyond
  * (callers difference pk_solve_protein_batch there, as phoskintime_amd.paramest.fit_rows_batch does). */
 int pk_protein_sens_available(int model, int n_sites);
 int pk_solve_protein_sens_batch(pk_ctx*, int model, int n_sites, int64_t B,

@@ -27,8 +27,19 @@ struct SensArgs {
   double* dflat;        // [B, F, P]
 };
 
+// LDS pointers carry their address space explicitly: a pointer that has been through a struct member or a select otherwise degrades to
+// a generic one, and its loads / stores to `flat_*` instructions (measured on the first version of the cube kernels: 7x slower)
+using lds_f64 = __attribute__((address_space(3))) double;
+
+// compiler-level ordering of the wave's LDS traffic (the hardware executes a wave's LDS instructions in order)
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct Park {            // thread-private LDS slots, slot-major (stride 64: conflict-free)
-  double* p;
+  lds_f64* p;
   __device__ __forceinline__ double ld(int k) const { return p[k * 64]; }
   __device__ __forceinline__ void st(int k, double v) const { p[k * 64] = v; }
 };
@@ -135,6 +146,39 @@ struct ChainSys {
     static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; nf = nf || nonfinite(pk.ld(K_C1 + i)) || nonfinite(pk.ld(K_DG + i)); });
     return nf;
   }
+  // ---- the interface sens_kernel uses
+  Park pk; int S_;
+  static constexpr size_t lds_doubles(int) { return (size_t)2 * NCOEF * 64; }
+  __device__ __forceinline__ void init(lds_f64* lds, const int lane, const int, const int c, const double* __restrict__ th, const int n, const int S) {
+    pk = Park{lds + lane}; S_ = S;
+    build(pk, 0, [&](int i) { return th[i]; }, 1.0, n);
+    build(pk, NCOEF, [&](int i) { return (i == c - 1) ? 1.0 : 0.0; }, 0.0, n);
+  }
+  __device__ __forceinline__ double cA() const { return pk.ld(K_A); }
+  __device__ __forceinline__ double dA() const { return pk.ld(NCOEF + K_A); }
+  // Y(ic) = element ic::value of the operand, out(ic, v) receives row ic::value of the product
+  template <class YF, class OF>
+  __device__ __forceinline__ void apply_base(YF&& Y, OF&& out, const double constA) const {
+    double a[NR], f[NR];
+    static_for<NR>([&](auto ic) { a[decltype(ic)::value] = Y(ic); });
+    apply(pk, 0, 1.0, constA, a, f, S_);
+    static_for<NR>([&](auto ic) { out(ic, f[decltype(ic)::value]); });
+  }
+  template <class YF, class OF>
+  __device__ __forceinline__ void apply_deriv(YF&& W, OF&& out, const double constA) const {
+    double a[NR], f[NR];
+    static_for<NR>([&](auto ic) { a[decltype(ic)::value] = W(ic); });
+    apply(pk, NCOEF, 0.0, constA, a, f, S_);
+    static_for<NR>([&](auto ic) { out(ic, f[decltype(ic)::value]); });
+  }
+  __device__ __forceinline__ void factor(const double q) { factor(pk, q, S_); }
+  template <class OF>
+  __device__ __forceinline__ void solve(const double (&r)[NR], OF&& out) const {
+    double x[NR];
+    solve(r, x, S_);
+    static_for<NR>([&](auto ic) { out(ic, x[decltype(ic)::value]); });
+  }
+  __device__ __forceinline__ bool coef_nonfinite() const { return coef_nonfinite(pk); }
 };
 
 // ---------------------------------------------------------------------------------------------- random model, n = NB <= 3 sites
@@ -233,21 +277,247 @@ struct CubeSys {
     static_for<NM>([&](auto mc) { constexpr int m = decltype(mc)::value; nf = nf || nonfinite(pk.ld(K_DG + m)) || nonfinite(pk.ld(K_CI + m)); });
     return nf;
   }
+  // ---- the interface sens_kernel uses
+  Park pk; int S_;
+  static constexpr size_t lds_doubles(int) { return (size_t)2 * NCOEF * 64; }
+  __device__ __forceinline__ void init(lds_f64* lds, const int lane, const int, const int c, const double* __restrict__ th, const int n, const int S) {
+    pk = Park{lds + lane}; S_ = S;
+    build(pk, 0, [&](int i) { return th[i]; }, 1.0, n);
+    build(pk, NCOEF, [&](int i) { return (i == c - 1) ? 1.0 : 0.0; }, 0.0, n);
+  }
+  __device__ __forceinline__ double cA() const { return pk.ld(K_A); }
+  __device__ __forceinline__ double dA() const { return pk.ld(NCOEF + K_A); }
+  // Y(ic) = element ic::value of the operand, out(ic, v) receives row ic::value of the product
+  template <class YF, class OF>
+  __device__ __forceinline__ void apply_base(YF&& Y, OF&& out, const double constA) const {
+    double a[NR], f[NR];
+    static_for<NR>([&](auto ic) { a[decltype(ic)::value] = Y(ic); });
+    apply(pk, 0, 1.0, constA, a, f, S_);
+    static_for<NR>([&](auto ic) { out(ic, f[decltype(ic)::value]); });
+  }
+  template <class YF, class OF>
+  __device__ __forceinline__ void apply_deriv(YF&& W, OF&& out, const double constA) const {
+    double a[NR], f[NR];
+    static_for<NR>([&](auto ic) { a[decltype(ic)::value] = W(ic); });
+    apply(pk, NCOEF, 0.0, constA, a, f, S_);
+    static_for<NR>([&](auto ic) { out(ic, f[decltype(ic)::value]); });
+  }
+  __device__ __forceinline__ void factor(const double q) { factor(pk, q, S_); }
+  template <class OF>
+  __device__ __forceinline__ void solve(const double (&r)[NR], OF&& out) const {
+    double x[NR];
+    solve(r, x, S_);
+    static_for<NR>([&](auto ic) { out(ic, x[decltype(ic)::value]); });
+  }
+  __device__ __forceinline__ bool coef_nonfinite() const { return coef_nonfinite(pk); }
 };
 
-template <class Sys, int GP> constexpr size_t sens_lds_bytes() { return (size_t)(2 * Sys::NCOEF * 64 + (64 / GP) * 2 * Sys::NR) * sizeof(double); }
+// ---------------------------------------------------------------------------------------------- random model, n = NB = 4, 5 sites
+// Here the inverse of M = I - q A (2^n x 2^n, dense after elimination) no longer fits one lane -- and it need not: it is the SAME matrix
+// for all 1 + P columns.  The group builds it ONCE per step in LDS (cooperative Gauss-Jordan, 2^2n / GP elements per lane and pivot,
+// wave-level ordering only) and every lane multiplies its own column by it, the matrix entries arriving as LDS broadcast reads.  This
+// is where forward sensitivities beat differencing outright: the differenced Jacobian inverts the matrix once per step in EACH of its
+// 1 + P replicas.  The derivative coefficients of a lane (d ci / d theta_c in {0, 1}, d dg / d theta_c in {0 .. n}) are packed into a
+// few registers (one bit / one nibble per row); the coefficients of theta live once per group in LDS.
+template <int NB, int GP_>
+struct CubeLdsSys {
+  static constexpr int NM = 1 << NB, NR = NM + 1, GP = GP_;
+  static_assert(GP >= NM, "one lane per matrix row in the pivot-row / pivot-column update");
+  static constexpr int GD = NM * NM + 2 * NM + 4;               // per group: inverse, dg[NM], ci[NM], cA cB cC (+ pad)
+  static constexpr size_t lds_doubles(int NG) { return (size_t)NG * GD; }
+  lds_f64* ainv; const lds_f64* dgp; const lds_f64* cip;
+  double cA_, cB, cC, dA_, dBc, dCc, winvR, qC;
+  uint32_t dcim, ddgw[(NM + 7) / 8];
+  int c_;
 
-// compiler-level ordering of the wave's LDS traffic (the hardware executes a wave's LDS instructions in order)
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __device__ __forceinline__ void init(lds_f64* lds, const int, const int g, const int c, const double* __restrict__ th, const int, const int) {
+    lds_f64* G = lds + g * GD;
+    ainv = G; lds_f64* dgw = G + NM * NM; lds_f64* ciw = dgw + NM; lds_f64* abc = ciw + NM;
+    dgp = dgw; cip = ciw; c_ = c;
+    if (c < NM) {                                               // lane m builds row m (models/randmod.py:122-247, lowest-set-bit quirk at :201)
+      const int m = c;
+      if (m == 0) {
+        double sumS = 0.0;
+        for (int j = 0; j < NB; ++j) sumS += th[4 + j];
+        dgw[0] = th[3] + sumS; ciw[0] = 0.0;
+        abc[0] = th[0]; abc[1] = th[1]; abc[2] = th[2];
+      } else {
+        const int lsb = __builtin_ctz(m);
+        ciw[m] = th[4 + lsb];
+        double out = 0.0;
+        for (int j = 0; j < NB; ++j) out += ((m >> j) & 1) ? 1.0 : th[4 + (j < lsb ? j : lsb)];
+        dgw[m] = out + th[4 + NB + m - 1];
+      }
+    }
+    wave_sync_lds();
+    cA_ = abc[0]; cB = abc[1]; cC = abc[2];
+    const int pidx = c - 1;                                     // -1 (base lane) and indices beyond P: all derivative coefficients zero
+    dA_ = (pidx == 0) ? 1.0 : 0.0; dBc = (pidx == 1) ? 1.0 : 0.0; dCc = (pidx == 2) ? 1.0 : 0.0;
+    dcim = 0;
+    for (int w = 0; w < (NM + 7) / 8; ++w) ddgw[w] = 0;
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      uint32_t ddg = 0, dci = 0;
+      if constexpr (m == 0) {
+        ddg = (pidx >= 3 && pidx < 4 + NB) ? 1u : 0u;            // dg[0] = D + sum_j S_j
+      } else {
+        constexpr int lsb = __builtin_ctz(m);
+        dci = (pidx == 4 + lsb) ? 1u : 0u;
+        static_for<NB>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (!((m >> j) & 1)) ddg += (pidx == 4 + (j < lsb ? j : lsb)) ? 1u : 0u;
+        });
+        ddg += (pidx == 4 + NB + m - 1) ? 1u : 0u;
+      }
+      dcim |= dci << m;
+      ddgw[m / 8] |= ddg << (4 * (m % 8));
+    });
+  }
+  __device__ __forceinline__ double cA() const { return cA_; }
+  __device__ __forceinline__ double dA() const { return dA_; }
+  template <int I> using IC = std::integral_constant<int, I>;
+  template <class YF, class OF>
+  __device__ __forceinline__ void apply_base(YF&& Y, OF&& out, const double constA) const {
+    const double Y0 = Y(IC<0>{});
+    out(IC<0>{}, __builtin_fma(-cB, Y0, constA));
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const double civ = cip[m];
+      double v = -dgp[m] * Y(IC<1 + m>{});
+      static_for<NB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (m & (1 << j)) v = __builtin_fma(civ, Y(IC<1 + (m ^ (1 << j))>{}), v);
+        else v += Y(IC<1 + (m ^ (1 << j))>{});
+      });
+      if constexpr (m == 0) v = __builtin_fma(cC, Y0, v);
+      out(IC<1 + m>{}, v);
+    });
+  }
+  template <class YF, class OF>
+  __device__ __forceinline__ void apply_deriv(YF&& W, OF&& out, const double constA) const {
+    const double W0 = W(IC<0>{});
+    out(IC<0>{}, __builtin_fma(-dBc, W0, constA));
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const double ddg = (double)((ddgw[m / 8] >> (4 * (m % 8))) & 15u);
+      double v = -ddg * W(IC<1 + m>{});
+      if constexpr (m != 0) {
+        double lo = 0.0;
+        static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr (m & (1 << j)) lo += W(IC<1 + (m ^ (1 << j))>{}); });
+        v += ((dcim >> m) & 1u) ? lo : 0.0;
+      } else {
+        v = __builtin_fma(dCc, W0, v);
+      }
+      out(IC<1 + m>{}, v);
+    });
+  }
+  __device__ __forceinline__ void factor(const double q) {
+    winvR = fast_rcp(__builtin_fma(q, cB, 1.0));
+    qC = q * cC;
+    wave_sync_lds();                                            // the previous step's products have read the old inverse
+    // element (i, j) with j = c mod 2^n and i = c / 2^n + (GP / 2^n) m, m = 0 .. EL - 1: a lane stays in ONE column, so the pivot row
+    // contributes one value per lane and pivot; the m-loops are unrolled (independent loads in flight)
+    constexpr int EL = NM * NM / GP, RS = GP / NM;
+    const int j = c_ & (NM - 1), ib = c_ >> NB;
+    static_for<EL>([&](auto mc) {
+      const int i = ib + RS * decltype(mc)::value, d = i ^ j;
+      double v;
+      if (d == 0) v = __builtin_fma(q, dgp[i], 1.0);
+      else if ((d & (d - 1)) == 0) v = -q * ((i & d) ? cip[i] : 1.0);
+      else v = 0.0;
+      ainv[i * NM + j] = v;
+    });
+    wave_sync_lds();
+#pragma unroll 1
+    for (int k = 0; k < NM; ++k) {                              // in-place Gauss-Jordan inverse, no pivoting (M-matrix)
+      const double rp = fast_rcp(ainv[k * NM + k]);
+      const double akj = ainv[k * NM + j];
+      double nv[EL];
+      static_for<EL>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int i = ib + RS * m;
+        nv[m] = __builtin_fma(-(ainv[i * NM + k] * rp), akj, ainv[i * NM + j]);
+      });
+      static_for<EL>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int i = ib + RS * m;
+        // off the pivot row / column: the update; pivot column: -a_ik / a_kk; pivot row: a_kj / a_kk; pivot: 1 / a_kk
+        double w = nv[m];
+        if (i == k) w = (j == k) ? rp : akj * rp;
+        else if (j == k) w = -(ainv[i * NM + k] * rp);
+        nv[m] = w;
+      });
+      wave_sync_lds();                                          // every lane has read the pivot row and column
+      static_for<EL>([&](auto mc) { constexpr int m = decltype(mc)::value; ainv[(ib + RS * m) * NM + j] = nv[m]; });
+      wave_sync_lds();
+    }
+  }
+  template <class OF>
+  __device__ __forceinline__ void solve(const double (&r)[NR], OF&& out) const {
+    const double zR = r[0] * winvR;
+    out(IC<0>{}, zR);
+    const double r0 = __builtin_fma(qC, zR, r[1]);              // the -q C z_R coupling of row P moved to the right-hand side
+    static_for<NM / 4>([&](auto bc) {                           // four rows at a time: four independent FMA chains per pass over r
+      constexpr int i0 = 4 * decltype(bc)::value;
+      double v[4];
+      static_for<4>([&](auto kc) { constexpr int k = decltype(kc)::value; v[k] = ainv[(i0 + k) * NM] * r0; });
+      static_for<NM - 1>([&](auto jc) {
+        constexpr int j = 1 + decltype(jc)::value;
+        static_for<4>([&](auto kc) { constexpr int k = decltype(kc)::value; v[k] = __builtin_fma(ainv[(i0 + k) * NM + j], r[1 + j], v[k]); });
+      });
+      static_for<4>([&](auto kc) { constexpr int k = decltype(kc)::value; out(IC<1 + i0 + k>{}, v[k]); });
+      __builtin_amdgcn_sched_barrier(0);                        // one block's loads in flight at a time
+    });
+  }
+  // the same product with the row loop ROLLED, the result going to thread-private LDS slots (stride 64): for the sizes whose columns live
+  // in LDS anyway -- one row's 2^n loads and FMAs in the code instead of 2^2n, registers bounded by one row
+  __device__ __forceinline__ void solve_slots(const double (&r)[NR], lds_f64* xs) const {
+    const double zR = r[0] * winvR;
+    xs[0] = zR;
+    const double r0 = __builtin_fma(qC, zR, r[1]);
+#pragma unroll 1
+    for (int i = 0; i < NM; i += 4) {                           // four rows per trip: four independent FMA chains hide the latency of one wave
+      const lds_f64* row = ainv + i * NM;
+      double v[4];
+      static_for<4>([&](auto kc) { constexpr int k = decltype(kc)::value; v[k] = row[k * NM] * r0; });
+      static_for<NM - 1>([&](auto jc) {
+        constexpr int j = 1 + decltype(jc)::value;
+        static_for<4>([&](auto kc) { constexpr int k = decltype(kc)::value; v[k] = __builtin_fma(row[k * NM + j], r[1 + j], v[k]); });
+      });
+      static_for<4>([&](auto kc) { constexpr int k = decltype(kc)::value; xs[(1 + i + k) * 64] = v[k]; });
+    }
+  }
+  __device__ __forceinline__ bool coef_nonfinite() const {
+    bool nf = nonfinite(cA_) || nonfinite(cB) || nonfinite(cC);
+    for (int m = 0; m < NM; ++m) nf = nf || nonfinite(dgp[m]) || nonfinite(cip[m]);
+    return nf;
+  }
+};
+
+// a column of NR doubles owned by one lane: in registers, or (for the largest systems) in thread-private LDS slots
+template <int NR, bool IN_LDS> struct Col;
+template <int NR> struct Col<NR, false> {
+  double v[NR];
+  __device__ __forceinline__ explicit Col(lds_f64*) {}
+  template <int I> __device__ __forceinline__ double get() const { return v[I]; }
+  template <int I> __device__ __forceinline__ void set(double x) { v[I] = x; }
+};
+template <int NR> struct Col<NR, true> {
+  lds_f64* p;
+  __device__ __forceinline__ explicit Col(lds_f64* slots) : p(slots) {}
+  template <int I> __device__ __forceinline__ double get() const { return p[I * 64]; }
+  template <int I> __device__ __forceinline__ void set(double x) { p[I * 64] = x; }
+};
+template <class Sys> constexpr bool sens_cols_in_lds() { return Sys::NR > 24; }
+
+template <class Sys, int GP> constexpr size_t sens_lds_bytes() {
+  return (Sys::lds_doubles(64 / GP) + (size_t)(64 / GP) * 2 * Sys::NR + (sens_cols_in_lds<Sys>() ? (size_t)2 * Sys::NR * 64 : 0)) * sizeof(double);
 }
 
 template <class Sys, int GP>
 __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
   using Tab = ResolventTab<PK_METHOD_LRP12>;
-  constexpr int NR = Sys::NR, NC = Sys::NCOEF, NG = 64 / GP;
+  constexpr int NR = Sys::NR, NG = 64 / GP;
   const SolveArgs& A = SA.s;
   const int lane = threadIdx.x, g = lane / GP, c = lane % GP;
   long long rep = (long long)blockIdx.x * NG + g;
@@ -258,29 +528,30 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
   const bool is_tan = (c >= 1 && c <= P);                    // lanes beyond 1 + P carry a zero column
 
   extern __shared__ __align__(16) double sens_lds[];
-  const Park pk{sens_lds + lane};
-  volatile double* const by = sens_lds + 2 * NC * 64 + g * 2 * NR;       // the base lane's y_n ...
-  volatile double* const bz = by + NR;                                     // ... and its latest stage vector
+  lds_f64* const lds0 = (lds_f64*)sens_lds;
+  lds_f64* const by = lds0 + Sys::lds_doubles(NG) + g * 2 * NR;              // the base lane's y_n ...  (ordering: wave_sync_lds, not volatile --
+  lds_f64* const bz = by + NR;                                               // ... and its latest stage vector     volatile loads would each wait out the LDS latency)
 
-  const double* __restrict__ th = A.theta + rep * P;
-  Sys::build(pk, 0, [&](int i) { return th[i]; }, 1.0, n);
-  Sys::build(pk, NC, [&](int i) { return (i == c - 1) ? 1.0 : 0.0; }, 0.0, n);
-  const double cA = pk.ld(Sys::K_A);                          // b = cA e_R
-  const double dA = pk.ld(NC + Sys::K_A);                     // b'_c
+  Sys sys;
+  sys.init(lds0, lane, g, c, A.theta + rep * P, n, S);    // coefficients of theta (shared by the group) and of the unit vector e_c
+  const double cA = sys.cA();                                 // b = cA e_R
+  const double dA = sys.dA();                                 // b'_c
 
   const double* y0p = A.y0 + (A.y0_batched ? rep * S : 0);
-  double y[NR];
-  static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; y[i] = (is_base && i < S) ? y0p[i] : 0.0; });
-  auto publish_y = [&]() {
+  constexpr bool CL = sens_cols_in_lds<Sys>();                // y_n and the solve's output column leave the registers where 5 NR doubles do not fit
+  lds_f64* const colmem = lds0 + Sys::lds_doubles(NG) + NG * 2 * NR + lane;
+  Col<NR, CL> y(colmem), x(colmem + (size_t)NR * 64);
+  static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; y.template set<i>((is_base && i < S) ? y0p[i] : 0.0); });
+  auto publish_y = [&]() __attribute__((always_inline)) {
     wave_sync_lds();
-    if (is_base) static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; by[i] = y[i]; });
+    if (is_base) static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; by[i] = y.template get<i>(); });
     wave_sync_lds();
   };
 
   const int T5 = T > 5 ? T - 5 : 0;
   double* const fl = A.flat + rep * F;
   double* const dfl = SA.dflat + rep * (long long)F * P + (c - 1);
-  auto emit = [&](const int k, const bool nan_fill) {
+  auto emit = [&](const int k, const bool nan_fill) __attribute__((always_inline)) {
     static_for<NR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if (i < S && i < 2 + n) {
@@ -290,7 +561,7 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
           const bool clipped = A.clip && (by[i] < 0.0);
           double r;
           if (nan_fill) r = __builtin_nan("");
-          else r = clipped ? 0.0 : y[i] * sc;
+          else r = clipped ? 0.0 : y.template get<i>() * sc;
           if (is_base) fl[fi] = r;
           else if (is_tan) dfl[(long long)fi * P] = r;
         }
@@ -303,7 +574,10 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
       if (A.n_steps) { A.n_steps[2 * rep] = acc; A.n_steps[2 * rep + 1] = rej; }
     }
   };
-  auto fail_from = [&](int k) { for (; k < T; ++k) emit(k, true); };
+  auto fail_from = [&](int k) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (; k < T; ++k) emit(k, true);
+  };
 
   publish_y();
   emit(0, false);
@@ -311,15 +585,15 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
   if (T < 2) { finish(status, 0, 0); return; }
 
   const double rtol = A.rtol, atol = A.atol;
-  auto norm = [&](const double (&e)[NR], const double (&ya)[NR], const double (&yb)[NR]) {
+  auto norm = [&](auto&& ef, auto&& yaf, auto&& ybf) __attribute__((always_inline)) {
     double m = 0.0;
     static_for<NR>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const double q = fabs(e[i]) * approx_rcp(__builtin_fma(rtol, fmax(fabs(ya[i]), fabs(yb[i])), atol));
+      const double q = fabs(ef(ic)) * approx_rcp(__builtin_fma(rtol, fmax(fabs(yaf(ic)), fabs(ybf(ic))), atol));
       m = (q > m || q != q) ? q : m;
     });
     return m;
   };
+  auto y_at = [&](auto ic) __attribute__((always_inline)) { return y.template get<decltype(ic)::value>(); };
 
   double tc = A.t[0];
   int k = 1;
@@ -327,15 +601,14 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
   double h;
   {
     double f0[NR];
-    Sys::apply(pk, 0, 1.0, cA, y, f0, S);
-    const double d0 = norm(y, y, y), d1 = norm(f0, y, y);
+    sys.apply_base(y_at, [&](auto ic, double v) { f0[decltype(ic)::value] = v; }, cA);
+    const double d0 = norm(y_at, y_at, y_at), d1 = norm([&](auto ic) { return f0[decltype(ic)::value]; }, y_at, y_at);
     h = (d0 > 1e-5 && d1 > 1e-5) ? 0.01 * d0 / d1 : 1e-6;
     if (A.h0 > 0.0) h = A.h0;
     if (!(h > 0.0) || h != h) h = 1e-6;
     h = bcast<GP, 0>(h);                                      // the base lane's estimate, for the whole group
   }
 
-  Sys sys;
   const double* const kB = Tab::B;                            // indexed by the (uniform) round counter: scalar loads from constant memory
   const double* const kE = Tab::E;
   bool after_reject = false;
@@ -344,14 +617,18 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
     const bool last = (tc + 1.0001 * h >= te);
     const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
     if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; fail_from(k); break; }
-    sys.factor(pk, Tab::GAM * hs, S);
+    sys.factor(Tab::GAM * hs);
 
     double z[NR], yn[NR], e[NR];
-    static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; z[i] = 0.0; yn[i] = y[i]; e[i] = 0.0; });
+    static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; z[i] = 0.0; yn[i] = y.template get<i>(); e[i] = 0.0; });
     // round `it`: the base lane forms stage it + 1, the tangent lanes stage it (they need the base's z_it, published in round it - 1).
     // Rounds 0 and 1 are special (right-hand sides from y), rounds 2 .. NS are one rolled loop: a single copy of the solve in the code,
     // registers bounded by one round
-    auto finish_round = [&](const int it) {
+    auto solve_to_x = [&](const double (&r)[NR]) __attribute__((always_inline)) {          // x = M^-1 r
+      if constexpr (CL) sys.solve_slots(r, x.p);
+      else sys.solve(r, [&](auto ic, double v) { x.template set<decltype(ic)::value>(v); });
+    };
+    auto finish_round = [&](const int it) __attribute__((always_inline)) {
       wave_sync_lds();                                          // every tangent lane has read bz
       if (is_base) static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; bz[i] = z[i]; });
       wave_sync_lds();
@@ -366,36 +643,35 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
     };
     {                                                           // round 0
       double r[NR];
-      Sys::apply(pk, 0, 1.0, cA, y, r, S);
-      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; r[i] = is_base ? r[i] * hs : 0.0; });
-      sys.solve(r, z, S);
+      sys.apply_base(y_at, [&](auto ic, double v) { r[decltype(ic)::value] = is_base ? v * hs : 0.0; }, cA);
+      solve_to_x(r);
+      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; z[i] = x.template get<i>(); });
       finish_round(0);
     }
     {                                                           // round 1
-      double r[NR], w[NR], d[NR];
-      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; w[i] = __builtin_fma(Tab::GAM, bz[i], by[i]); });
-      Sys::apply(pk, NC, 0.0, dA, w, d, S);                     // A'_c (y + g z_1) + b'_c
-      Sys::apply(pk, 0, 1.0, 0.0, y, r, S);                     // A y'_c
-      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; r[i] = is_base ? z[i] : hs * (r[i] + d[i]); });
-      sys.solve(r, z, S);
+      double r[NR];
+      sys.apply_base(y_at, [&](auto ic, double v) { r[decltype(ic)::value] = v; }, 0.0);                  // A y'_c
+      sys.apply_deriv([&](auto ic) { constexpr int i = decltype(ic)::value; return __builtin_fma(Tab::GAM, bz[i], by[i]); },
+                      [&](auto ic, double v) { constexpr int i = decltype(ic)::value; r[i] = is_base ? z[i] : hs * (r[i] + v); }, dA);   // + A'_c (y + g z_1) + b'_c
+      solve_to_x(r);
+      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; z[i] = x.template get<i>(); });
       finish_round(1);
     }
     const double gh = is_base ? 0.0 : Tab::GAM * hs;
 #pragma unroll 1
     for (int it = 2; it <= Tab::NS; ++it) {
-      double r[NR], w[NR], d[NR];
-      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; w[i] = bz[i]; });
-      Sys::apply(pk, NC, 0.0, 0.0, w, d, S);                    // A'_c z_it
-      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; r[i] = __builtin_fma(gh, d[i], z[i]); });
-      sys.solve(r, z, S);
+      sys.apply_deriv([&](auto ic) { return bz[decltype(ic)::value]; },
+                      [&](auto ic, double v) { constexpr int i = decltype(ic)::value; z[i] = __builtin_fma(gh, v, z[i]); }, 0.0);              // z'_it + g h A'_c z_it
+      solve_to_x(z);
+      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; z[i] = x.template get<i>(); });
       finish_round(it);
     }
 
-    double err = norm(e, y, yn);
+    double err = norm([&](auto ic) { return e[decltype(ic)::value]; }, y_at, [&](auto ic) { return yn[decltype(ic)::value]; });
     err = gmax<GP>(err, lane);
     if (err != err || err > 1e300) {
       ++nrej; after_reject = true; h = 0.1 * hs;
-      bool nf = sys.coef_nonfinite(pk);
+      bool nf = sys.coef_nonfinite();
       static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; nf = nf || nonfinite(by[i]); });
       if (nf) { status |= PK_ST_NONFINITE; fail_from(k); break; }
       continue;
@@ -405,7 +681,7 @@ __global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
     double hnew = hs * fast_rcp(fac);
     if (err <= 1.0) {
       ++nacc;
-      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; y[i] = yn[i]; });
+      static_for<NR>([&](auto ic) { constexpr int i = decltype(ic)::value; y.template set<i>(yn[i]); });
       publish_y();
       tc += hs;
       if (after_reject) hnew = fmin(hnew, hs);

@@ -82,7 +82,7 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     n_active integrations, each carrying its P tangents; exact derivative of the discrete solution) -- ``"fd"``: SciPy's '2-point'
     forward differences, one launch of n_active * P perturbed replicas on the throughput kernels, which is what the reference's
     curve_fit does call by call.  ``"auto"`` (default) takes "sens" where a kernel exists (``batch.sens_available``: distmod / succmod
-    n <= 14, randmod n <= 3) and the solver options are the default method's, else "fd".  Either way one more launch per damping round
+    n <= 14, randmod n <= 5) and the solver options are the default method's, else "fd".  Either way one more launch per damping round
     evaluates the trial points.  ``device_algebra=True``: residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU (torch ops on the
     `flat` tensors the kernel wrote); per iteration and row only P x P + P doubles come back and a P-vector of trial parameters goes up.
     ``False``: round 1's path -- every ``flat`` vector (n_active * P x Nd doubles per iteration) crosses PCIe and numpy does the algebra.

@@ -8,7 +8,7 @@ from oracle import protein_models as pm
 
 def main():
     t = pm.TIME_POINTS
-    for model, n in (("distmod", 4), ("distmod", 8), ("distmod", 14), ("succmod", 4), ("succmod", 14), ("randmod", 2), ("randmod", 3)):
+    for model, n in (("distmod", 4), ("distmod", 8), ("distmod", 14), ("succmod", 4), ("succmod", 14), ("randmod", 2), ("randmod", 3), ("randmod", 4), ("randmod", 5)):
         mid = pm.MODEL_IDS[model]; S, P = pm.n_states(mid, n), pm.n_params(mid, n)
         rng = np.random.default_rng(1)
         for B in (64, 4096, 65536):
@@ -23,7 +23,7 @@ def main():
             print("%s n=%d P=%d B=%d: sens %.2f ms (steps %.0f)   differenced %.2f ms (steps %.0f)   ratio %.2f" % (
                 model, n, P, B, ts * 1e3, ns[:, 0].mean(), tf * 1e3, nq[:, 0].mean(), tf / ts), flush=True)
     # the LM driver
-    for model, n, R in (("distmod", 4, 48), ("distmod", 8, 480), ("randmod", 3, 48), ("succmod", 14, 96)):
+    for model, n, R in (("randmod", 4, 48), ("randmod", 5, 48), ("distmod", 4, 48), ("distmod", 8, 480), ("randmod", 3, 48), ("succmod", 14, 96)):
         mid = pm.MODEL_IDS[model]; S, P = pm.n_states(mid, n), pm.n_params(mid, n)
         rng = np.random.default_rng(3)
         truth = rng.uniform(0.5, 1.5, size=P); y0 = np.ones(S)
