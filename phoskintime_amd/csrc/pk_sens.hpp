@@ -52,6 +52,7 @@ struct ChainSys {
   static constexpr int NR = NS + 2;
   static constexpr int NCOEF = 2 * NR + 1;
   static constexpr int K_C1 = 0, K_DG = NR, K_A = 2 * NR;
+  static constexpr int MIN_WAVES = NS <= 3 ? 3 : NS <= 9 ? 2 : 1;      // measured: a third wave at NS = 5 costs spills and time
   double winv[NR], fx[NR], qq, cC;
 
   static __host__ __device__ constexpr int n_params(int n) { return 4 + 2 * n; }
@@ -189,6 +190,7 @@ struct CubeSys {
   static constexpr int NM = 1 << NB;
   static constexpr int NR = NM + 1;
   static constexpr int NCOEF = 2 * NM + 3;
+  static constexpr int MIN_WAVES = NB <= 2 ? 3 : 1;                     // NB = 3 holds the 8 x 8 inverse in registers
   static constexpr int K_DG = 0, K_CI = NM, K_A = 2 * NM, K_B = 2 * NM + 1, K_C = 2 * NM + 2;
   double a[NM][NM], winvR, qC;
 
@@ -322,6 +324,7 @@ struct CubeSys {
 template <int NB, int GP_>
 struct CubeLdsSys {
   static constexpr int NM = 1 << NB, NR = NM + 1, GP = GP_;
+  static constexpr int MIN_WAVES = 1;
   static_assert(GP >= NM, "one lane per matrix row in the pivot-row / pivot-column update");
   static constexpr int GD = NM * NM + 2 * NM + 4;               // per group: inverse, dg[NM], ci[NM], cA cB cC (+ pad)
   static constexpr size_t lds_doubles(int NG) { return (size_t)NG * GD; }
@@ -514,8 +517,12 @@ template <class Sys, int GP> constexpr size_t sens_lds_bytes() {
   return (Sys::lds_doubles(64 / GP) + (size_t)(64 / GP) * 2 * Sys::NR + (sens_cols_in_lds<Sys>() ? (size_t)2 * Sys::NR * 64 : 0)) * sizeof(double);
 }
 
+// waves per SIMD the register allocation must leave room for: the kernel is a chain of dependent f64 operations (a lone wave keeps its SIMD
+// busy 38 % of the time: profiles/r02_g_sens_*), so the small systems trade registers for a second / third resident wave
+template <class Sys> constexpr int sens_min_waves() { return Sys::MIN_WAVES; }
+
 template <class Sys, int GP>
-__global__ __launch_bounds__(64) void sens_kernel(const SensArgs SA) {
+__global__ __launch_bounds__(64, sens_min_waves<Sys>()) void sens_kernel(const SensArgs SA) {
   using Tab = ResolventTab<PK_METHOD_LRP12>;
   constexpr int NR = Sys::NR, NG = 64 / GP;
   const SolveArgs& A = SA.s;

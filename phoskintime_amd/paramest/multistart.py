@@ -130,9 +130,15 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         rr = (f - t_d[rows_d]) * isig_d[rows_d]
         return torch.where(torch.isfinite(rr), rr, torch.full_like(rr, 1e6))            # failed solves are very bad, not fatal
 
-    sens_kw = {k: v for k, v in solver_kw.items() if k in ("rtol", "atol", "h0", "max_steps", "clip_nonneg", "normalize")}
-    sens_ok = batch.sens_available(model, num_psites) and all(k in sens_kw or v is None or (k == "method" and v in ("lrp12", 5)) or k == "kernel"
-                                                               for k, v in solver_kw.items())
+    # the sensitivity kernel integrates with the default method only and takes the tolerance / clipping options of the plain solve;
+    # any other explicit solver option (another method, a linear solver, the stage form) keeps the differenced Jacobian
+    sens_opts = ("rtol", "atol", "h0", "max_steps", "clip_nonneg", "normalize")
+    sens_kw = {k: v for k, v in solver_kw.items() if k in sens_opts}
+
+    def _default_for_sens(k, v):
+        return v is None or k in sens_opts or k == "kernel" or (k == "method" and v in ("lrp12", 5))
+
+    sens_ok = batch.sens_available(model, num_psites) and all(_default_for_sens(k, v) for k, v in solver_kw.items())
     if jacobian == "auto":
         jacobian = "sens" if sens_ok else "fd"
     if jacobian not in ("sens", "fd"):

@@ -2,6 +2,7 @@
 # Round-2 profiles, ONE WORKLOAD PER PROFILE (run on the GPU box via gpurun):   bash tools/profile_r02.sh <what> <tag>
 #   config3   bench.py's default command: rocprofv3 kernel stats of the full timed region + separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ, f64 mix)
 #   network5  bench.py --only-network (BASELINE config 5 shape at rtol = atol = 1e-8): kernel stats + SQ counters of exactly that launch
+#   sens / sens_rand   the forward-sensitivity kernel (distmod n = 8, B = 65536 / randmod n = 4, B = 16384)
 #   tpr       the thread-per-replica kernel at BASELINE config 1 size (distmod n = 4, B = 524288): kernel stats + HBM / SQ counters
 set -u
 WHAT=${1:-config3}
@@ -15,6 +16,8 @@ case $WHAT in
   config3) CMD="python3 $REPO/bench.py --no-cpu-baseline --no-secondary"; CMDS="$CMD --steps 3 --warmup 1" ;;
   network5) CMD="python3 $REPO/bench.py --only-network"; CMDS="$CMD" ;;
   tpr) CMD="python3 $REPO/tools/gpu_one.py 0 4 524288 20"; CMDS="python3 $REPO/tools/gpu_one.py 0 4 524288 3" ;;
+  sens) CMD="python3 $REPO/tools/gpu_sens_one.py distmod 8 65536 10"; CMDS="python3 $REPO/tools/gpu_sens_one.py distmod 8 65536 2" ;;
+  sens_rand) CMD="python3 $REPO/tools/gpu_sens_one.py randmod 4 16384 5"; CMDS="python3 $REPO/tools/gpu_sens_one.py randmod 4 16384 2" ;;
   *) echo "unknown workload $WHAT"; exit 2 ;;
 esac
 cd /tmp
