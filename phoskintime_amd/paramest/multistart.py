@@ -70,7 +70,8 @@ class RowsFit:
 
 
 def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None,
-                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra="auto", jacobian="auto", **solver_kw) -> RowsFit:
+                   max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra="auto", jacobian="auto", trial_levels="auto",
+                   **solver_kw) -> RowsFit:
     """R independent bounded least-squares problems in lockstep: row k fits ``[flat(p) ; lam_k / P * p**2]`` to ``[target_k ; 0]`` with
     weights ``sigma_k`` from the start point ``P0[k]``.  Rows may be the starts of one multistart fit, the (lambda, weight) grid of
     ``find_best_lambda``, bootstrap replicates, different proteins of the same size -- or any mix.
@@ -83,7 +84,10 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     forward differences, one launch of n_active * P perturbed replicas on the throughput kernels, which is what the reference's
     curve_fit does call by call.  ``"auto"`` (default) takes "sens" where a kernel exists (``batch.sens_available``: distmod / succmod
     n <= 14, randmod n <= 5) and the solver options are the default method's, else "fd".  Either way one more launch per damping round
-    evaluates the trial points.  ``device_algebra=True``: residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU (torch ops on the
+    evaluates the trial points, ``trial_levels`` consecutive damping values (mu, 4 mu, 16 mu) per row and launch ("auto": three while at
+    most 256 rows are pending, else one); the first acceptable one is taken, as a one-try-per-launch loop (``trial_levels=1``) would.
+
+    ``device_algebra=True``: residuals, Jacobians and the normal equations J^T J, J^T r are formed on the GPU (torch ops on the
     `flat` tensors the kernel wrote); per iteration and row only P x P + P doubles come back and a P-vector of trial parameters goes up.
     ``False``: round 1's path -- every ``flat`` vector (n_active * P x Nd doubles per iteration) crosses PCIe and numpy does the algebra.
     ``"auto"`` (default) picks by the size of that transfer (> 2 MB: device).  Measured on MI355X (bench.py `lm_fit`): at 1 MB per Jacobian
@@ -220,51 +224,68 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         active[idx[done]] = False
         DD = np.maximum(np.sqrt(np.einsum("kpp->kp", A)), 1e-12)                       # Marquardt scaling (the reference's x_scale='jac')
         pend = np.where(~done)[0]                                                      # positions inside idx
-        # Levenberg-Marquardt trial steps, still in lockstep: every pending row proposes one step, ONE launch evaluates them all;
-        # the rejected ones raise their damping and go again
-        for _ in range(12):
+        # Levenberg-Marquardt trial steps, still in lockstep.  The sequential rule -- try mu; if the step is rejected, try 4 mu, 16 mu, ...
+        # (up to 12 tries) -- is kept, but `trial_levels` consecutive damping values of every pending row are evaluated in ONE launch
+        # and the first acceptable one in that order is taken: the same accepted steps as one try per launch, a third of the launches
+        # (these batches are small: the fits are bound by launch latency and synchronisation, not by the solves)
+        tries = 0
+        while tries < 12:
             if pend.size == 0:
                 break
+            # "auto": small rounds are latency-bound (three levels per launch); beyond ~256 pending rows the wasted solves cost more than
+            # the launches saved (measured: 480 rows of distmod n = 8, 65 ms with one level against 74 ms with three)
+            K = (3 if pend.size <= 256 else 1) if trial_levels == "auto" else int(trial_levels)
+            K = min(K, 12 - tries)
+            tries += K
             rows = idx[pend]
+            m = pend.size
             fr = free[pend]
-            Af = A[pend] * (fr[:, :, None] & fr[:, None, :])
-            dg = np.where(fr, mu[rows, None] * DD[pend] ** 2, 1.0)                     # fixed variables: identity row, zero step
-            Af[:, np.arange(P), np.arange(P)] += dg
+            Af0 = A[pend] * (fr[:, :, None] & fr[:, None, :])
             rhs = -gfree[pend]
-            try:
-                step = np.linalg.solve(Af, rhs[:, :, None])[:, :, 0]
-            except np.linalg.LinAlgError:
-                step = np.zeros_like(rhs)
-                for k_ in range(pend.size):
-                    try:
-                        step[k_] = np.linalg.solve(Af[k_], rhs[k_])
-                    except np.linalg.LinAlgError:
-                        pass
-            step = np.where(np.isfinite(step), step, 0.0)
-            trial = np.clip(p[rows] + step, lb[rows], ub[rows])
+            trials = np.empty((K, m, P))
+            for lv in range(K):
+                Af = Af0.copy()
+                dg = np.where(fr, (mu[rows, None] * 4.0 ** lv) * DD[pend] ** 2, 1.0)   # fixed variables: identity row, zero step
+                Af[:, np.arange(P), np.arange(P)] += dg
+                try:
+                    step = np.linalg.solve(Af, rhs[:, :, None])[:, :, 0]
+                except np.linalg.LinAlgError:
+                    step = np.zeros_like(rhs)
+                    for k_ in range(m):
+                        try:
+                            step[k_] = np.linalg.solve(Af[k_], rhs[k_])
+                        except np.linalg.LinAlgError:
+                            pass
+                step = np.where(np.isfinite(step), step, 0.0)
+                trials[lv] = np.clip(p[rows] + step, lb[rows], ub[rows])
             if device_algebra:
                 rows_d = torch.as_tensor(rows, device=dev)
-                rn_d = residuals_dev(torch.as_tensor(trial, device=dev), rows_d)
-                cn = (0.5 * (rn_d * rn_d).sum(dim=1)).cpu().numpy()
+                rn_d = residuals_dev(torch.as_tensor(trials.reshape(K * m, P), device=dev), rows_d.repeat(K)).reshape(K, m, Nr)
+                cn = (0.5 * (rn_d * rn_d).sum(dim=2)).cpu().numpy()                    # [K, m]
             else:
-                rn = residuals(trial, rows)
-                cn = 0.5 * np.sum(rn * rn, axis=1)
-            dp = trial - p[rows]
-            pred = -(np.einsum("kp,kp->k", g[pend], dp) + 0.5 * np.einsum("kp,kpq,kq->k", dp, A[pend], dp))
-            rho = np.where(pred > 0, (cost[rows] - cn) / np.where(pred > 0, pred, 1.0), -1.0)
-            ok = (cn < cost[rows]) & (rho > 1e-4)
-            dx = np.linalg.norm(dp, axis=1); dc = cost[rows] - cn
-            conv = ok & ((dc <= ftol * np.maximum(cn, 1e-300)) | (dx <= xtol * (xtol + np.linalg.norm(trial, axis=1))))
+                rn = residuals(trials.reshape(K * m, P), np.tile(rows, K)).reshape(K, m, Nr)
+                cn = 0.5 * np.sum(rn * rn, axis=2)
+            dp = trials - p[rows][None]
+            pred = -(np.einsum("kp,lkp->lk", g[pend], dp) + 0.5 * np.einsum("lkp,kpq,lkq->lk", dp, A[pend], dp))
+            rho = np.where(pred > 0, (cost[rows][None] - cn) / np.where(pred > 0, pred, 1.0), -1.0)
+            okl = (cn < cost[rows][None]) & (rho > 1e-4)                                # [K, m]
+            ok = okl.any(axis=0)
+            lvl = np.argmax(okl, axis=0)                                               # first acceptable damping level of each row
+            sel = (lvl, np.arange(m))
+            trial, cns, rhos, dps = trials[sel], cn[sel], rho[sel], dp[sel]
+            dx = np.linalg.norm(dps, axis=1); dc = cost[rows] - cns
+            conv = ok & ((dc <= ftol * np.maximum(cns, 1e-300)) | (dx <= xtol * (xtol + np.linalg.norm(trial, axis=1))))
             acc = rows[ok]
-            p[acc], cost[acc] = trial[ok], cn[ok]
+            p[acc], cost[acc] = trial[ok], cns[ok]
             if device_algebra:
                 if acc.size:
-                    r_d[rows_d[torch.as_tensor(ok, device=dev)]] = rn_d[torch.as_tensor(ok, device=dev)]
+                    ok_d = torch.as_tensor(ok, device=dev)
+                    r_d[rows_d[ok_d]] = rn_d[torch.as_tensor(lvl, device=dev), torch.arange(m, device=dev)][ok_d]
             else:
-                r[acc] = rn[ok]
-            mu[acc] = np.maximum(mu[acc] * np.where(rho[ok] > 0.75, 1.0 / 3.0, 1.0), 1e-12)
+                r[acc] = rn[sel][ok]
+            mu[acc] = np.maximum(mu[acc] * 4.0 ** lvl[ok] * np.where(rhos[ok] > 0.75, 1.0 / 3.0, 1.0), 1e-12)
             active[rows[conv]] = False
-            mu[rows[~ok]] *= 4.0
+            mu[rows[~ok]] *= 4.0 ** K
             pend = pend[~ok]
         active[idx[pend]] = False          # no acceptable step within the damping budget: converged / stalled
     r_out = r_d.cpu().numpy() if device_algebra else r

@@ -128,3 +128,25 @@ def test_levenberg_marquardt_on_sensitivities_matches_the_differenced_fit(eng, m
     # both reach the data (the parameters themselves are only weakly identified: compare in data space)
     assert np.median(np.abs(pred(s) - target).max(axis=1)) < 1e-5
     assert np.median(s.cost) <= 10.0 * np.median(f.cost) + 1e-12
+
+
+def test_batched_damping_levels_take_the_same_steps_as_one_try_per_launch(eng):
+    """`trial_levels` = 3 evaluates mu, 4 mu, 16 mu in one launch and takes the first acceptable one: the accepted steps, hence the
+    iterates, are those of the sequential rule (up to the rounding of a solve that ran in a batch of another size)."""
+    from phoskintime_amd.paramest import multistart as ms
+    model, n = "distmod", 3
+    mid = pm.MODEL_IDS[model]
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    rng = np.random.default_rng(5)
+    truth = rng.uniform(0.5, 1.5, size=P)
+    y0 = np.ones(S); t = pm.TIME_POINTS
+    target = eng.solve_ode_batch(model, truth[None], y0, n, t, want_sol=False).flat.cpu().numpy()[0]
+    target = target * (1.0 + 0.01 * rng.standard_normal(target.size))
+    P0 = truth * rng.uniform(0.2, 4.0, size=(16, P))                 # far starts: some first tries are rejected
+    lb, ub = np.full(P, 1e-3), np.full(P, 10.0)
+    kw = dict(bounds=(lb, ub), max_iter=8, kernel="group")
+    a = ms.fit_rows_batch(model, n, t, P0, y0, target, trial_levels=1, **kw)
+    b = ms.fit_rows_batch(model, n, t, P0, y0, target, trial_levels=3, **kw)
+    np.testing.assert_allclose(a.p, b.p, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(a.cost, b.cost, rtol=1e-6, atol=1e-14)
+    assert b.n_launches <= a.n_launches and b.n_solves >= a.n_solves
