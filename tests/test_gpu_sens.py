@@ -150,3 +150,27 @@ def test_batched_damping_levels_take_the_same_steps_as_one_try_per_launch(eng):
     np.testing.assert_allclose(a.p, b.p, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(a.cost, b.cost, rtol=1e-6, atol=1e-14)
     assert b.n_launches <= a.n_launches and b.n_solves >= a.n_solves
+
+
+def test_sensitivity_edge_shapes(eng):
+    """T = 1 (only the initial time: flat is data, zero Jacobian), T <= 5 (no R block in flat), B = 0, one replica, batched y0 at randmod n = 4."""
+    import torch
+    n, mid = 4, 2
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    rng = np.random.default_rng(3)
+    th = rng.uniform(0.3, 2.0, size=(3, P)); y0 = rng.uniform(0.5, 1.5, size=(3, S))
+    r1 = eng.solve_ode_sens_batch("randmod", th, y0, n, [0.0])
+    assert r1.flat.shape == (3, pm.flatten_observables(mid, np.zeros((1, S)), n).size) and r1.dflat.shape == (3, r1.flat.shape[1], P)
+    assert np.all(r1.dflat.cpu().numpy() == 0.0) and int(r1.status.abs().sum()) == 0
+    t3 = np.array([0.0, 0.7, 3.0])
+    r3 = eng.solve_ode_sens_batch("randmod", th, y0, n, t3, rtol=1e-9, atol=1e-11)
+    assert r3.flat.shape[1] == 3 + 3 * n                    # T <= 5: P(t) and the n site series only
+    for b in range(3):
+        ref = pm.flatten_observables(mid, np.clip(pm.solve_exact_lti(mid, th[b], y0[b], n, t3), 0, None), n)
+        assert pm.band_error(r3.flat[b].cpu().numpy(), ref) < 0.1
+    one = eng.solve_ode_sens_batch("randmod", th[1], y0[1], n, t3, rtol=1e-9, atol=1e-11)      # 1-D theta: one replica
+    assert np.array_equal(one.dflat.cpu().numpy()[0], r3.dflat.cpu().numpy()[1])
+    r0 = eng.solve_ode_sens_batch("randmod", np.zeros((0, P)), np.ones(S), n, t3)
+    assert r0.flat.shape == (0, 3 + 3 * n) and r0.dflat.shape == (0, 3 + 3 * n, P)
+    with pytest.raises(ValueError):
+        eng.solve_ode_sens_batch("randmod", np.ones((2, P + 1)), np.ones(S), n, t3)
