@@ -11,8 +11,9 @@
  *   model      0 = distmod (models/distmod.py), 1 = succmod (models/succmod.py), 2 = randmod (models/randmod.py)
  *   state      y = [R, P, X_1..X_m], m = n_sites (dist/succ) or 2^n_sites - 1 (rand); S = 2 + m.  Up to 64 states a replica is a lane
  *              group of a wavefront; beyond that (distmod / succmod n_sites 63..1276, randmod n_sites 7..20) one workgroup owns a
- *              replica: distmod / succmod keep the default LRP12 with exact structured solves, randmod integrates with the
- *              order-4 additive method ARK4(3)6L[2]SA on the n-cube at 0.02 x the requested tolerances (csrc/pk_wide.hpp)
+ *              replica: distmod / succmod keep the default LRP12 with exact structured solves; randmod n_sites = 7 keeps LRP12 too, the
+ *              128 x 128 inverse spread over the registers of the workgroup (csrc/pk_rand_dense.hpp); randmod n_sites >= 8 integrates with
+ *              the order-4 additive method ARK4(3)6L[2]SA on the n-cube at 0.02 x the requested tolerances (csrc/pk_wide.hpp)
  *   theta      [A, B, C, D, S_1..S_n, D_1..D_m], P = 4 + n + m      (reference unpack_params, distmod.py:68-91,
  *              succmod.py:94-112, randmod.py:88-119); batched as a row-major [B, P] f64 matrix
  *   return     0 = ok; < 0 = argument / runtime error (see pk_last_error); never throws or aborts.

@@ -216,7 +216,11 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
     PK_HIP(c, hipSetDevice(c->device));
     if (model == PK_MODEL_RAND) {
       if (!resolvent_method(o.method) || o.stage_form)
-        return fail(c, PK_ERR_UNSUPPORTED, "randmod n_sites >= 7 integrates with the Rosenbrock-W kernel: method must be LRP12 / LRP8 / RODAS4 (resolvent form)");
+        return fail(c, PK_ERR_UNSUPPORTED, "randmod n_sites >= 7: method must be LRP12 / LRP8 / RODAS4 in resolvent form (n = 7: LRP12 with the dense inverse; beyond: additive Runge-Kutta on the n-cube)");
+      if (pk::rand_dense_available(n_sites)) {                // n = 7: exact solves, the default method's step counts (pk_rand_dense.hpp)
+        PK_HIP(c, pk::launch_rand_dense(a, c->stream));
+        return PK_OK;
+      }
       double* scr = nullptr;
       if (!pk::wide_rand_in_lds(n_sites)) {
         rc = arena_reserve(c, c->scratch, pk::wide_rand_scratch_bytes(n_sites, B));

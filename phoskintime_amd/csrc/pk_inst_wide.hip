@@ -1,5 +1,6 @@
 // Instantiations + launchers of the workgroup-per-replica kernels (pk_wide.hpp) for systems beyond one wavefront's lane groups.
 #include "pk_wide.hpp"
+#include "pk_rand_dense.hpp"
 #include "pk_launch.hpp"
 #include <atomic>
 #include <cstdlib>
@@ -24,6 +25,17 @@ hipError_t allow_lds(K fn, std::atomic<uint64_t>& ready) {
   return hipSuccess;
 }
 }  // namespace
+
+// randmod n = 7 only: the 2^n x 2^n inverse must fit the register file of one workgroup (128 KB of a CU's 512 KB; n = 8 would need all of
+// it).  PK_WIDE_RAND_DENSE=0 (read once) sends n = 7 back to the approximate-factorisation kernel (tests exercise both).
+bool rand_dense_available(int n_sites) {
+  static const bool on = [] { const char* v = getenv("PK_WIDE_RAND_DENSE"); return !(v && v[0] == '0'); }();
+  return on && n_sites == 7;
+}
+hipError_t launch_rand_dense(const SolveArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((rand_dense_kernel<7>), dim3((unsigned)a.B), dim3(rand_dense_threads<7>()), rand_dense_lds_bytes(a.n_sites), st, a);
+  return hipGetLastError();
+}
 
 bool wide_chain_fits(int S, int n) { return wide_chain_lds_bytes(S, n) <= kLdsMax; }
 

@@ -34,6 +34,8 @@ hipError_t launch_sens(const SensArgs&, int model, hipStream_t);
 // workgroup-per-replica kernels for systems beyond 64 rows (pk_wide.hpp)
 bool wide_chain_fits(int S, int n_sites);                                   // distmod / succmod: 15 LDS vectors of S doubles
 hipError_t launch_wide_chain(const SolveArgs&, int model, hipStream_t);     // LRP12, exact solves
+bool rand_dense_available(int n_sites);                                    // randmod n = 7: LRP12 with the dense inverse in registers (pk_rand_dense.hpp)
+hipError_t launch_rand_dense(const SolveArgs&, hipStream_t);
 bool wide_rand_in_lds(int n_sites);                                         // randmod n >= 7: 9 LDS vectors of 2^n + 1 doubles (n <= 10 / 11)
 size_t wide_rand_scratch_bytes(int n_sites, long long B);                   // 0 when the vectors fit LDS
 hipError_t launch_wide_rand(const SolveArgs&, double* scratch, hipStream_t);   // ROS34PW2-W on the n-cube
