@@ -3,6 +3,7 @@
 #   config3   bench.py's default command: rocprofv3 kernel stats of the full timed region + separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ, f64 mix)
 #   network5  bench.py --only-network (BASELINE config 5 shape at rtol = atol = 1e-8): kernel stats + SQ counters of exactly that launch
 #   sens / sens_rand   the forward-sensitivity kernel (distmod n = 8, B = 65536 / randmod n = 4, B = 16384)
+#   rand7     randmod n = 7, B = 1024, theta ~ U(0, 20): the dense LRP12 kernel (pk_rand_dense.hpp)
 #   tpr       the thread-per-replica kernel at BASELINE config 1 size (distmod n = 4, B = 524288): kernel stats + HBM / SQ counters
 set -u
 WHAT=${1:-config3}
@@ -18,6 +19,7 @@ case $WHAT in
   tpr) CMD="python3 $REPO/tools/gpu_one.py 0 4 524288 20"; CMDS="python3 $REPO/tools/gpu_one.py 0 4 524288 3" ;;
   sens) CMD="python3 $REPO/tools/gpu_sens_one.py distmod 8 65536 10"; CMDS="python3 $REPO/tools/gpu_sens_one.py distmod 8 65536 2" ;;
   sens_rand) CMD="python3 $REPO/tools/gpu_sens_one.py randmod 4 16384 5"; CMDS="python3 $REPO/tools/gpu_sens_one.py randmod 4 16384 2" ;;
+  rand7) CMD="python3 $REPO/tools/gpu_one.py 2 7 1024 10"; CMDS="python3 $REPO/tools/gpu_one.py 2 7 1024 2" ;;
   *) echo "unknown workload $WHAT"; exit 2 ;;
 esac
 cd /tmp
