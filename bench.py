@@ -489,6 +489,18 @@ def secondary_legs(args, dev, tt, cpu):
             torch.cuda.synchronize(dev)
             dto = (time.perf_counter() - t1) / reps
             other[label] = {"replicas_per_s": Bo / dto, "ms": 1e3 * dto, "flagged": int((oo.status != 0).sum()), "mean_steps": float(oo.n_steps[:, 0].double().mean())}
+        # forward sensitivities: flat and d flat / d theta of every replica from one launch (csrc/pk_sens.hpp)
+        for label, mdl, nn, Bo in (("sensitivities_distmod_n8_B65536", "distmod", 8, 65536), ("sensitivities_randmod_n4_B4096", "randmod", 4, 4096)):
+            Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
+            tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.2, 2.0, (Bo, Po)), device=dev)
+            batch.solve_ode_sens_batch(mdl, tho[:64], np.ones(So), nn, tt)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                rs = batch.solve_ode_sens_batch(mdl, tho, np.ones(So), nn, tt)
+            torch.cuda.synchronize(dev)
+            dto = (time.perf_counter() - t1) / 3
+            other[label] = {"jacobians_per_s": Bo / dto, "ms": 1e3 * dto, "columns": Po, "flagged": int((rs.status != 0).sum()), "mean_steps": float(rs.n_steps[:, 0].double().mean())}
         res["other_protein_configs"] = other
     except Exception as e:
         res["other_protein_configs"] = {"error": repr(e)}
