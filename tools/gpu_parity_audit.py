@@ -22,6 +22,8 @@ def main():
     cases = [("distmod", n) for n in (1, 4, 14, 30, 62)] + [("succmod", n) for n in (1, 4, 14, 30, 62)] + [("randmod", n) for n in (1, 2, 3, 4, 5, 6)]
     if part >= 0:
         cases = cases[part::3]
+    if len(sys.argv) > 3:                                   # explicit list: model:n,model:n,...
+        cases = [(c.split(":")[0], int(c.split(":")[1])) for c in sys.argv[3].split(",")]
     dists = {"U(0.05,2)": lambda r, s: r.uniform(0.05, 2.0, s), "U(0,20)": lambda r, s: r.uniform(0.0, 20.0, s),
              "logU(1e-3,1e2)": lambda r, s: 10.0 ** r.uniform(-3.0, 2.0, s)}
     logf = open(pathlib.Path(__file__).resolve().parents[1] / "gpurun_out" / ("parity_audit_%d.log" % max(part, 0)), "a")
