@@ -197,6 +197,10 @@ int pk_solve_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
                                 const double* t, int T, const pk_solver_opts* opts,
                                 double* sol, double* flat, double* metric, int metric_id,
                                 int32_t* status, int32_t* n_steps);
+int pk_solve_protein_sens_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
+                                     const double* theta, const double* y0, int y0_is_batched,
+                                     const double* t, int T, const pk_solver_opts* opts,
+                                     double* flat, double* dflat, int32_t* status, int32_t* n_steps);
 int pk_rhs_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,
                               const double* theta, const double* y, double* dydt);
 int pk_jacobian_protein_batch_host(pk_ctx*, int model, int n_sites, int64_t B,

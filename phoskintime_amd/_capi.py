@@ -64,7 +64,7 @@ SYMBOLS = (
     "pk_version", "pk_create", "pk_create_error", "pk_destroy", "pk_last_error", "pk_set_stream", "pk_use_own_stream", "pk_synchronize", "pk_default_opts", "pk_workspace_stats",
     "pk_protein_n_states", "pk_protein_n_params", "pk_protein_flat_len",
     "pk_solve_protein_batch", "pk_solve_protein_sens_batch", "pk_protein_sens_available", "pk_rhs_protein_batch", "pk_jacobian_protein_batch", "pk_steady_state_protein_batch", "pk_morris_build_batch", "pk_morris_effects_batch", "pk_score_fit_batch",
-    "pk_solve_protein_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
+    "pk_solve_protein_batch_host", "pk_solve_protein_sens_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
     "pk_time_solve_protein_batch", "pk_measure_hbm_gbs", "pk_measure_fp64_fma_tflops",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
@@ -107,8 +107,8 @@ def load():
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [i32, i32]
     lib.pk_protein_flat_len.restype = i32; lib.pk_protein_flat_len.argtypes = [i32, i32, i32]
     lib.pk_protein_sens_available.restype = i32; lib.pk_protein_sens_available.argtypes = [i32, i32]
-    lib.pk_solve_protein_sens_batch.restype = i32
-    lib.pk_solve_protein_sens_batch.argtypes = [vp, i32, i32, i64, vp, vp, i32, vp, i32, optp, vp, vp, vp, vp]
+    for f in ("pk_solve_protein_sens_batch", "pk_solve_protein_sens_batch_host"):
+        getattr(lib, f).restype = i32; getattr(lib, f).argtypes = [vp, i32, i32, i64, vp, vp, i32, vp, i32, optp, vp, vp, vp, vp]
     solve_args = [vp, i32, i32, i64, vp, vp, i32, vp, i32, optp, vp, vp, vp, i32, vp, vp]
     for f in ("pk_solve_protein_batch", "pk_solve_protein_batch_host"):
         getattr(lib, f).restype = i32; getattr(lib, f).argtypes = solve_args

@@ -432,6 +432,31 @@ int pk_solve_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, co
   return h.download();
 }
 
+int pk_solve_protein_sens_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y0, int y0_is_batched,
+                                     const double* t, int T, const pk_solver_opts* opts, double* flat, double* dflat, int32_t* status,
+                                     int32_t* n_steps) {
+  if (!c) return PK_ERR_ARG;
+  int rc = check_model(c, model, n_sites);
+  if (rc) return rc;
+  if (B < 0 || T < 1) return fail(c, PK_ERR_ARG, "B must be >= 0 and T >= 1");
+  if (!pk::sens_available(model, n_sites))
+    return fail(c, PK_ERR_UNSUPPORTED, "forward sensitivities: distmod / succmod n_sites <= 14, randmod n_sites <= 5 (difference the batched solve beyond)");
+  if (B == 0) return PK_OK;
+  if (!theta || !y0 || !t || !flat || !dflat) return fail(c, PK_ERR_ARG, "theta, y0, t, flat and dflat must be non-null");
+  const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), F = pk_protein_flat_len(model, n_sites, T);
+  PK_HIP(c, hipSetDevice(c->device));
+  HostCall h(c);
+  const size_t ny0 = (y0_is_batched ? (size_t)B : 1) * S;
+  const size_t o_th = h.add_in(theta, (size_t)B * P * 8), o_y0 = h.add_in(y0, ny0 * 8), o_t = h.add_in(t, (size_t)T * 8);
+  const size_t o_flat = h.add_out(flat, (size_t)B * F * 8), o_df = h.add_out(dflat, (size_t)B * F * P * 8), o_st = h.add_out(status, (size_t)B * 4),
+               o_ns = h.add_out(n_steps, (size_t)B * 8);
+  if ((rc = h.upload())) return rc;
+  rc = pk_solve_protein_sens_batch(c, model, n_sites, B, h.dev<const double>(o_th), h.dev<const double>(o_y0), y0_is_batched, h.dev<const double>(o_t), T, opts,
+                                   h.dev<double>(o_flat), h.dev<double>(o_df), h.dev<int32_t>(o_st), h.dev<int32_t>(o_ns));
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+  return h.download();
+}
+
 int pk_rhs_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y, double* dydt) {
   if (!c) return PK_ERR_ARG;
   int rc = check_model(c, model, n_sites);

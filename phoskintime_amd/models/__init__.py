@@ -17,12 +17,14 @@ def _bind(name: str):
 
 model_module = _bind(config.ODE_MODEL)
 solve_ode = model_module.solve_ode
+solve_ode_jac = model_module.solve_ode_jac          # not in the reference: flat and its parameter Jacobian from one integration
 
 
 def set_model(name: str):
     """Re-bind ``models.solve_ode`` (the reference needs a config.toml edit and a fresh interpreter for this)."""
-    global model_module, solve_ode
+    global model_module, solve_ode, solve_ode_jac
     model_module = _bind(name)
     solve_ode = model_module.solve_ode
+    solve_ode_jac = model_module.solve_ode_jac
     config.ODE_MODEL = name
     return model_module

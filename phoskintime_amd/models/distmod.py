@@ -4,7 +4,7 @@ Same names and signatures (``ode_core`` distmod.py:7, ``unpack_params`` :68, ``s
 libphoskin_hip.so (model id 0)."""
 import numpy as np
 
-from ._common import pack_params, rhs_host, solve_host
+from ._common import pack_params, rhs_host, solve_host, solve_jac_host
 
 MODEL_ID = 0
 
@@ -26,3 +26,9 @@ def solve_ode(params, init_cond, num_psites, t):
     """(sol[T, S] clipped >= 0 (and / y0 if NORMALIZE_MODEL_OUTPUT), flat = [R(t5..), P(t0..), sites site-major]).
     Reference distmod.py:93-134 (odeint at SciPy defaults); here the engine's default integrator: adaptive LRP12 (order-11 L-stable resolvent method, include/phoskin.h) at rtol 1e-6 / atol 1e-8."""
     return solve_host(MODEL_ID, params, init_cond, num_psites, t)
+
+
+def solve_ode_jac(params, init_cond, num_psites, t):
+    """(flat, d flat / d params [F, P]) from ONE integration (forward sensitivities) -- an addition to the reference's surface: the ``jac=``
+    callable for scipy.optimize.curve_fit around ``solve_ode`` (paramest/normest.py:167-326 lets curve_fit difference it)."""
+    return solve_jac_host(MODEL_ID, params, init_cond, num_psites, t)

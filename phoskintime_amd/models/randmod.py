@@ -7,7 +7,7 @@ from functools import lru_cache
 
 import numpy as np
 
-from ._common import pack_params, rhs_host, solve_host
+from ._common import pack_params, rhs_host, solve_host, solve_jac_host
 
 MODEL_ID = 2
 
@@ -49,3 +49,9 @@ def ode_system(y, t, A, B, C, D, num_sites, S, Ddeg, mono_idx=None, forward=None
 def solve_ode(popt, y0, num_sites, t):
     """Reference randmod.py:249-305 contract: (sol, [R(t5..), P, first num_sites phospho columns site-major])."""
     return solve_host(MODEL_ID, popt, y0, num_sites, t)
+
+
+def solve_ode_jac(popt, y0, num_sites, t):
+    """(flat, d flat / d params [F, P]) from ONE integration (forward sensitivities) -- an addition to the reference's surface: the ``jac=``
+    callable for scipy.optimize.curve_fit around ``solve_ode`` (paramest/normest.py:167-326 lets curve_fit difference it)."""
+    return solve_jac_host(MODEL_ID, popt, y0, num_sites, t)

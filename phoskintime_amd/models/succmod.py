@@ -3,7 +3,7 @@
 ``ode_core`` succmod.py:9, ``unpack_params`` :94, ``solve_ode`` :114."""
 import numpy as np
 
-from ._common import pack_params, rhs_host, solve_host
+from ._common import pack_params, rhs_host, solve_host, solve_jac_host
 
 MODEL_ID = 1
 
@@ -24,3 +24,9 @@ def unpack_params(params, num_psites):
 def solve_ode(params, init_cond, num_psites, t):
     """Reference succmod.py:114-152 contract: (sol, flat)."""
     return solve_host(MODEL_ID, params, init_cond, num_psites, t)
+
+
+def solve_ode_jac(params, init_cond, num_psites, t):
+    """(flat, d flat / d params [F, P]) from ONE integration (forward sensitivities) -- an addition to the reference's surface: the ``jac=``
+    callable for scipy.optimize.curve_fit around ``solve_ode`` (paramest/normest.py:167-326 lets curve_fit difference it)."""
+    return solve_jac_host(MODEL_ID, params, init_cond, num_psites, t)

@@ -174,3 +174,28 @@ def test_sensitivity_edge_shapes(eng):
     assert r0.flat.shape == (0, 3 + 3 * n) and r0.dflat.shape == (0, 3 + 3 * n, P)
     with pytest.raises(ValueError):
         eng.solve_ode_sens_batch("randmod", np.ones((2, P + 1)), np.ones(S), n, t3)
+
+
+def test_dropin_jacobian_callable_for_scipy_curve_fit(eng):
+    """models.solve_ode_jac through the host-pointer entry point: the `jac=` callable a maintainer hands to scipy.optimize.curve_fit around
+    models.solve_ode (paramest/normest.py:167-326).  curve_fit with it reaches the synthetic truth; the callable equals the device-pointer
+    entry point bit for bit."""
+    from scipy.optimize import curve_fit
+    from phoskintime_amd import models
+    models.set_model("distmod")
+    n = 2
+    truth = np.array([1.2, 0.4, 0.9, 0.15, 0.8, 0.3, 0.5, 0.25])
+    y0 = np.ones(4); t = pm.TIME_POINTS
+    _, target = models.solve_ode(truth, y0, n, t)
+    flat, J = models.solve_ode_jac(truth, y0, n, t)
+    dev = eng.solve_ode_sens_batch("distmod", truth[None], y0, n, t)
+    assert np.array_equal(J, dev.dflat.cpu().numpy()[0]) and np.array_equal(flat, dev.flat.cpu().numpy()[0])
+    f = lambda tt, *p: models.solve_ode(np.array(p), y0, n, t)[1]
+    jac = lambda tt, *p: models.solve_ode_jac(np.array(p), y0, n, t)[1]
+    p0 = truth * 1.3
+    popt, _ = curve_fit(f, t, target, p0=p0, jac=jac, bounds=(0.0, 20.0), maxfev=2000)
+    assert np.max(np.abs(f(t, *popt) - target)) < 1e-6
+    models.set_model("randmod")
+    with pytest.raises(Exception):
+        models.solve_ode_jac(np.ones(pm.n_params(2, 6)), np.ones(pm.n_states(2, 6)), 6, t)      # no kernel at n = 6: loud, not silent
+    models.set_model("distmod")
