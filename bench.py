@@ -455,6 +455,18 @@ def secondary_legs(args, dev, tt, cpu):
                                       "gpu_us_median": float(lat[lat.size // 2]), "gpu_us_p90": float(lat[int(0.9 * lat.size)]), "gpu_us_min": float(lat[0]),
                                       "cpu_port_us": cpu.get("config1_cpu_us"), "workspace": ctx.workspace_stats(),
                                       "note": "one call = pack into the page-locked buffer -> 1 H2D -> kernel (1 workgroup) -> 1 D2H -> sync; no hipMalloc / hipFree"}
+        # the same protein's value AND parameter Jacobian in one call (models.solve_ode_jac: the jac= callable for curve_fit); the reference's
+        # curve_fit differences solve_ode 1 + P times for it
+        for _ in range(20):
+            models.solve_ode_jac(th1, y01, 4, TGRID)
+        latj = []
+        for _ in range(200):
+            t1 = time.perf_counter(); models.solve_ode_jac(th1, y01, 4, TGRID); latj.append(time.perf_counter() - t1)
+        latj = np.sort(np.array(latj)) * 1e6
+        res["config1_single_call"]["jacobian_call_gpu_us_median"] = float(latj[latj.size // 2])
+        if cpu.get("config1_cpu_us"):
+            res["config1_single_call"]["jacobian_cpu_port_us_derived"] = 13 * cpu["config1_cpu_us"]
+            res["config1_single_call"]["jacobian_note"] = "CPU figure = (1 + P) x cpu_port_us: the 13 solve_ode calls of scipy's 2-point differencing at P = 12"
         models.set_model("randmod")
     except Exception as e:
         res["config1_single_call"] = {"error": repr(e)}
