@@ -2,7 +2,7 @@
 For every model size and three parameter distributions: B replicas on the GPU (default options), every one compared with
 oracle.protein_models.solve_exact_lti on the host cores.  Prints one line per case: worst band error (rtol 1e-6 / atol 1e-8), the share of
 replicas beyond 0.5 and 1.0 band widths, flagged replicas, mean steps.  Usage: python tools/gpu_parity_audit.py [B] [part]  (part 0 / 1 / 2)"""
-import sys, time, pathlib
+import sys, time, pathlib, zlib
 import multiprocessing as mp
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
@@ -33,7 +33,7 @@ def main():
     for model, n in cases:
         mid = pm.MODEL_IDS[model]; S, P = pm.n_states(mid, n), pm.n_params(mid, n)
         for dname, draw in dists.items():
-            rng = np.random.default_rng(hash((model, n, dname)) % (2 ** 31))
+            rng = np.random.default_rng(zlib.crc32(('%s %d %s' % (model, n, dname)).encode()))
             Bc = B if S <= 33 else max(64, B // 4)
             th = draw(rng, (Bc, P)); y0 = np.ones(S) if dname != "U(0.05,2)" else rng.uniform(0.2, 3.0, S)
             t0 = time.perf_counter()
