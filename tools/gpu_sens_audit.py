@@ -20,7 +20,7 @@ def _jac(args):
     for c in range(th.size):
         # five-point stencil: a two-point difference has a truncation error (h t)^2 / 6 on parameters that set a time scale (t up to 960),
         # which at h = 1e-5 is 1e-5 ... 1e-4 of the derivative -- above what is being measured here
-        h = 2e-4 * max(1e-1, min(1.0, abs(th[c])))
+        h = 1e-3 * max(1e-1, min(1.0, abs(th[c])))             # (smaller steps measure the rounding noise of the matrix exponentials: 1e-5 at 2e-5)
         f = lambda s: _flat(mid, np.where(np.arange(th.size) == c, th + s * h, th), y0, n)
         cols.append((f(-2.0) - 8.0 * f(-1.0) + 8.0 * f(1.0) - f(2.0)) / (12.0 * h))
     return np.stack(cols, axis=1)
