@@ -199,3 +199,24 @@ def test_dropin_jacobian_callable_for_scipy_curve_fit(eng):
     with pytest.raises(Exception):
         models.solve_ode_jac(np.ones(pm.n_params(2, 6)), np.ones(pm.n_states(2, 6)), 6, t)      # no kernel at n = 6: loud, not silent
     models.set_model("distmod")
+
+
+def test_clipped_entries_have_zero_derivative(eng):
+    """flat clips negative values to 0 (reference np.clip(sol, 0, None)); the Jacobian follows: zero where the value was clipped, the
+    plain derivative elsewhere -- compared with differences of the oracle's CLIPPED output."""
+    n, mid = 3, 0
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    rng = np.random.default_rng(9)
+    th = rng.uniform(0.3, 2.0, size=(2, P))
+    y0 = np.ones(S); y0[1] = -0.8; y0[3] = -0.4                    # protein and one site start negative: clipped for a while
+    t = pm.TIME_POINTS
+    r = eng.solve_ode_sens_batch("distmod", th, y0, n, t, rtol=1e-9, atol=1e-11)
+    flat, d = r.flat.cpu().numpy(), r.dflat.cpu().numpy()
+    assert (flat == 0.0).any() and (flat >= 0.0).all()
+    for b in range(2):
+        ref = _oracle_jac(mid, th[b], y0, n, t)
+        clipped = flat[b] == 0.0
+        assert np.all(d[b][clipped] == 0.0)
+        ref_f = _oracle_flat(mid, th[b], y0, n, t)
+        interior = (~clipped) & (ref_f > 1e-6)                      # away from the kink, where the difference quotient is a derivative
+        assert np.max(np.abs(d[b][interior] - ref[interior]) / (1.0 + np.abs(ref[interior]))) < SENS_RTOL
