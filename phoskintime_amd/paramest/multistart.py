@@ -120,15 +120,16 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     dev = torch.device("cuda", batch.get_context().device)
     if device_algebra == "auto":
         device_algebra = R * P * Nd * 8 > (2 << 20)                   # bytes of `flat` one Jacobian evaluation would move over PCIe
-    if device_algebra:
-        t_d = torch.as_tensor(tfull, device=dev); isig_d = torch.as_tensor(1.0 / sig, device=dev); lam_d = torch.as_tensor(lam / P, device=dev)
-        y0_d = torch.as_tensor(np.array(y0, dtype=float, copy=True), device=dev)
+    # per-fit constants go to HBM once (a host array handed to a launch is uploaded by that launch: 35 us each, several per iteration)
+    t_d = torch.as_tensor(tfull, device=dev); isig_d = torch.as_tensor(1.0 / sig, device=dev); lam_d = torch.as_tensor(lam / P, device=dev)
+    y0_d = torch.as_tensor(np.array(y0, dtype=float, copy=True), device=dev)
+    tp_d = torch.as_tensor(np.ascontiguousarray(np.atleast_1d(np.asarray(time_points, dtype=float))), device=dev)
 
     def residuals_dev(Pm_d, rows_d):
         """Pm_d [m, P] (GPU) for the problems rows_d [m] (GPU index tensor) -> weighted residuals [m, Nr] on the GPU (one launch)."""
         nonlocal n_solves, n_launches
         theta = torch.exp(Pm_d) if log_space else Pm_d
-        flat = batch.solve_ode_batch(model, theta, y0_d[rows_d] if y0_rows else y0_d, num_psites, time_points, want_sol=False, want_flat=True, **solver_kw).flat
+        flat = batch.solve_ode_batch(model, theta, y0_d[rows_d] if y0_rows else y0_d, num_psites, tp_d, want_sol=False, want_flat=True, **solver_kw).flat
         n_solves += Pm_d.shape[0]; n_launches += 1
         f = torch.cat([flat, lam_d[rows_d, None] * Pm_d * Pm_d], dim=1) if use_reg else flat
         rr = (f - t_d[rows_d]) * isig_d[rows_d]
@@ -155,21 +156,20 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         nonlocal n_solves, n_launches
         Pm_d = torch.as_tensor(Pm, device=dev)
         theta = torch.exp(Pm_d) if log_space else Pm_d
-        y0s = (y0_d[torch.as_tensor(rows, device=dev)] if y0_rows else y0_d) if device_algebra else (y0[rows] if y0_rows else y0)
-        res = batch.solve_ode_sens_batch(model, theta, y0s, num_psites, time_points, **sens_kw)
+        rows_d = torch.as_tensor(rows, device=dev)
+        res = batch.solve_ode_sens_batch(model, theta, y0_d[rows_d] if y0_rows else y0_d, num_psites, tp_d, **sens_kw)
         n_solves += Pm_d.shape[0]; n_launches += 1
         D = res.dflat * theta[:, None, :] if log_space else res.dflat                   # chain rule of theta = exp(p)
         if use_reg:
-            lam_rows = torch.as_tensor(lam[rows] / P, device=dev)
-            D = torch.cat([D, torch.diag_embed(2.0 * lam_rows[:, None] * Pm_d)], dim=1)
-        D = D * torch.as_tensor(1.0 / sig[rows], device=dev)[:, :, None]
+            D = torch.cat([D, torch.diag_embed(2.0 * lam_d[rows_d, None] * Pm_d)], dim=1)
+        D = D * isig_d[rows_d][:, :, None]
         return torch.where(torch.isfinite(D), D, torch.zeros_like(D))                   # a failed solve contributes no direction
 
     def residuals(Pm, rows):
         """Host path: Pm [m, P] for the problems `rows` [m] -> weighted residuals [m, Nr]  (one launch, flat over PCIe)."""
         nonlocal n_solves, n_launches
         theta = np.exp(Pm) if log_space else Pm
-        flat = batch.solve_ode_batch(model, theta, y0[rows] if y0_rows else y0, num_psites, time_points, want_sol=False, want_flat=True,
+        flat = batch.solve_ode_batch(model, theta, y0_d[torch.as_tensor(rows, device=dev)] if y0_rows else y0_d, num_psites, tp_d, want_sol=False, want_flat=True,
                                      **solver_kw).flat.cpu().numpy()
         n_solves += Pm.shape[0]; n_launches += 1
         f = np.concatenate([flat, (lam[rows, None] / P) * Pm ** 2], axis=1) if use_reg else flat
@@ -204,8 +204,9 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
                 r_at = r_d[torch.as_tensor(idx, device=dev)]
             else:
                 r_at = torch.as_tensor(r[idx], device=dev)
-            A = torch.bmm(Jd.transpose(1, 2), Jd).cpu().numpy()
-            g = torch.bmm(Jd.transpose(1, 2), r_at[:, :, None])[:, :, 0].cpu().numpy()
+            # J^T [J | r] in one product, one copy back: [k, P, P + 1]
+            AG = torch.bmm(Jd.transpose(1, 2), torch.cat([Jd, r_at[:, :, None]], dim=2)).cpu().numpy()
+            A, g = np.ascontiguousarray(AG[:, :, :P]), np.ascontiguousarray(AG[:, :, P])
         elif device_algebra:
             idx_d = torch.as_tensor(idx, device=dev)
             rp = residuals_dev(torch.as_tensor(Pp, device=dev), idx_d.repeat_interleave(P)).reshape(idx.size, P, Nr)
