@@ -100,7 +100,7 @@ def test_wide_sizes_against_closed_form(eng, model, n):
 def test_wide_failures_are_flagged_not_fatal_and_unsupported_options_raise(eng):
     from phoskintime_amd._capi import ST_MAXSTEPS, ST_NONFINITE, PhoskinError
     rng = np.random.default_rng(1)
-    for model, n in ((pm.DIST, 80), (pm.SUCC, 80), (pm.RAND, 7)):
+    for model, n in ((pm.DIST, 80), (pm.SUCC, 80), (pm.RAND, 7), (pm.RAND, 8)):      # n = 7: dense LRP12 kernel; n = 8: n-cube kernel
         P, S = pm.n_params(model, n), pm.n_states(model, n)
         th = rng.uniform(0.1, 3.0, (4, P))
         good = _np(eng.solve_ode_batch(model, th, np.ones(S), n, pm.TIME_POINTS).sol)
