@@ -57,6 +57,8 @@ hipError_t launch_wide_chain(const SolveArgs& a, int model, hipStream_t st) {
 
 // scratch == nullptr: the vectors live in LDS (caller checked wide_rand_in_lds); else one row of `stride` doubles per replica in HBM
 // the order-4 additive method is the default (PK_WIDE_RAND_ROSW=1, read once, selects round-2's first version: ROS34PW2-W)
+// PK_WIDE_RAND_DRIFT=0 (read once) switches the drift removal of the n-cube kernel off (A/B runs, tests of the plain path)
+static int wide_rand_drift() { static const int on = [] { const char* v = getenv("PK_WIDE_RAND_DRIFT"); return (v && v[0] == '0') ? 0 : 1; }(); return on; }
 static bool wide_rand_ark() { static const bool rosw = [] { const char* v = getenv("PK_WIDE_RAND_ROSW"); return v && atoi(v) == 1; }(); return !rosw; }
 bool wide_rand_in_lds(int n) { return n <= 16 && wide_rand_lds_bytes(n, true, wide_rand_ark()) <= kLdsMax; }
 size_t wide_rand_scratch_bytes(int n, long long B) { return wide_rand_in_lds(n) ? 0 : (size_t)B * wide_rand_scratch_doubles(n, wide_rand_ark()) * sizeof(double); }
@@ -70,9 +72,9 @@ static hipError_t launch_wide_rand_m(const SolveArgs& a, double* scratch, hipStr
   if (!scratch) {
     static std::atomic<uint64_t> ready{0};
     if ((e = allow_lds(wide_rand_kernel<true, ARK>, ready)) != hipSuccess) return e;
-    hipLaunchKernelGGL((wide_rand_kernel<true, ARK>), dim3((unsigned)a.B), dim3(nt), wide_rand_lds_bytes(n, true, ARK), st, a, (double*)nullptr, (size_t)0);
+    hipLaunchKernelGGL((wide_rand_kernel<true, ARK>), dim3((unsigned)a.B), dim3(nt), wide_rand_lds_bytes(n, true, ARK), st, a, (double*)nullptr, (size_t)0, wide_rand_drift());
   } else {
-    hipLaunchKernelGGL((wide_rand_kernel<false, ARK>), dim3((unsigned)a.B), dim3(256), wide_rand_lds_bytes(n, false, ARK), st, a, scratch, wide_rand_scratch_doubles(n, ARK));
+    hipLaunchKernelGGL((wide_rand_kernel<false, ARK>), dim3((unsigned)a.B), dim3(256), wide_rand_lds_bytes(n, false, ARK), st, a, scratch, wide_rand_scratch_doubles(n, ARK), wide_rand_drift());
   }
   return hipSuccess;
 }

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void wide_chain_kernel(const SolveArgs A) {
 // =====================================================================================================================================
 // random model on the n-cube.  Vectors of S = 2^n + 1 doubles: y, Ys, U0..U3, f, loss (index 1 + mask), dinv : 9 vectors
 // ROS34PW2: y, Ys, U0..U3, f, loss, dinv = 9 vectors; ARK436: y, Y, w, v, g r, R3..R6, the two running sums, loss, dinv = 13 vectors
-__host__ __device__ constexpr int wide_rand_vectors(bool ark) { return ark ? 13 : 9; }
+__host__ __device__ constexpr int wide_rand_vectors(bool ark) { return ark ? 16 : 9; }        // ARK: + s, u, p(t) of the drift removal
 __host__ __device__ inline size_t wide_rand_small_doubles(int n) { return (size_t)n + (2 + n) + 24; }                 // Sr, prevv, red
 __host__ __device__ inline size_t wide_rand_lds_bytes(int n, bool ldsv, bool ark) {                                    // + lvl, binomials [, ord]
   const size_t NM = (size_t)1 << n, S = NM + 1;
@@ -319,7 +319,7 @@ __host__ __device__ inline size_t wide_rand_lds_bytes(int n, bool ldsv, bool ark
 __host__ __device__ inline size_t wide_rand_scratch_doubles(int n, bool ark) { const size_t NM = (size_t)1 << n, S = NM + 1; return wide_rand_vectors(ark) * S + (NM + 1) / 2 + 1; }
 
 template <bool LDSV, bool ARK>
-__global__ __launch_bounds__(256) void wide_rand_kernel(const SolveArgs A, double* __restrict__ scratch, const size_t stride) {
+__global__ __launch_bounds__(256) void wide_rand_kernel(const SolveArgs A, double* __restrict__ scratch, const size_t stride, const int drift_on) {
   using namespace rosw_tab;
   constexpr int NV = wide_rand_vectors(ARK);
   extern __shared__ __align__(16) double lds[];
@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void wide_rand_kernel(const SolveArgs A, doubl
   int* ord = LDSV ? binom + 21 * 21 : reinterpret_cast<int*>(vec + (size_t)NV * S);      // masks in popcount-level order
   const double* y0p = A.y0 + (A.y0_batched ? rep * S : 0);
   const double cA = th[0], cB = th[1], cC = th[2], cD = th[3];
+  double cAe = cA;                                    // the constant of the mRNA row as the integrator sees it (0 once the drift is removed)
 
   // ---- tables: binomials, popcount levels, masks in level order
   if (tid == 0) {
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void wide_rand_kernel(const SolveArgs A, doubl
   auto rhs_into = [&](const double* Y, double* dst, const int nu, const double* coef) {
     for (int row = tid; row < S; row += nt) {
       double v;
-      if (row == 0) v = __builtin_fma(-cB, Y[0], cA);
+      if (row == 0) v = __builtin_fma(-cB, Y[0], cAe);
       else {
         const int m = row - 1;
         double lo = 0.0, hi = 0.0;
@@ -420,16 +421,86 @@ __global__ __launch_bounds__(256) void wide_rand_kernel(const SolveArgs A, doubl
       __syncthreads();
     }
   };
+  const double* pofs = nullptr;                       // drift removal: the integrated vector is y - p(t); tolerances stay relative to y
   auto norm_of = [&](const double* e, const double* ya, const double* yb) {
     auto mx = [](double p, double r) { return (p > r || p != p) ? p : r; };
     double m = 0.0;
-    for (int row = tid; row < S; row += nt) m = mx(m, fabs(e[row]) / __builtin_fma(rtol, fmax(fabs(ya[row]), fabs(yb[row])), atol));
+    for (int row = tid; row < S; row += nt) {
+      const double po = pofs ? pofs[row] : 0.0;
+      m = mx(m, fabs(e[row]) / __builtin_fma(rtol, fmax(fabs(ya[row] + po), fabs(yb[row] + po)), atol));
+    }
     return wg_max(m, red);
   };
 
   double tc = A.t[0];
   int k = 1;
   double te = A.t[1];
+  const double t0 = tc;
+  // ---- drift removal (ARK only).  The splitting error of the approximate factorisation is proportional to the increments, so a replica
+  // whose solution never comes to rest -- mRNA degradation B ~ 0: R(t) and with it every state keep moving over the whole time span -- pays
+  // 10-40x the steps of its neighbours (tools/gpu_wide_outlier.py).  That motion is known in closed form.  With phi(tau) = (1 - e^{-B tau}) / B,
+  //   R(tau) = R0 + (A - B R0) phi,      cube: y_c = s - u phi + w,     (M_c + B I) u = C (A - B R0) e_0,    M_c s = -C R0 e_0 - u,
+  // the remainder w obeys the HOMOGENEOUS w' = M_c w and comes to rest at the cube's own rates (the form is cancellation-free for B -> 0,
+  // where phi -> tau).  The two linear systems are solved by the sweeps this kernel already has, iterated to 1e-14 (defect correction:
+  // a regular splitting of an M-matrix); if an iteration does not converge the replica is integrated as it stands.
+  bool drift = false;
+  [[maybe_unused]] double* sv = nullptr; [[maybe_unused]] double* uv = nullptr; [[maybe_unused]] double* pv = nullptr;
+  const double R0 = y0p[0];
+  auto phi_of = [&](const double tau) {
+    const double x = cB * tau;
+    return (x < 1e-5) ? tau * (1.0 - 0.5 * x + x * x * (1.0 / 6.0)) : -expm1(-x) / cB;
+  };
+  auto set_p = [&](const double tau) {                  // p(t) into pv; ends with a barrier
+    const double ph = phi_of(tau);
+    for (int row = tid; row < S; row += nt) pv[row] = (row == 0) ? __builtin_fma(cA - cB * R0, ph, R0) : __builtin_fma(-uv[row], ph, sv[row]);
+    __syncthreads();
+  };
+  if constexpr (ARK) {
+    sv = extra + 4 * (size_t)S; uv = extra + 5 * (size_t)S; pv = extra + 6 * (size_t)S;
+    double ml = 1e300;
+    for (int row = 1 + tid; row < S; row += nt) ml = fmin(ml, loss[row]);
+    ml = -wg_max(-ml, red);
+    const bool want = drift_on && cB >= 0.0 && cB < 0.25 * ml && !nonfinite(cA) && !nonfinite(cC) && !nonfinite(R0) && !nonfinite(ml);
+    if (want) {
+      double* res = U[0]; double* dx = U[1];
+      // x <- W^-1 r,  W = diag(loss - shift) - F - K = -(M_c + shift I),  r = r1 e_0 (+ radd);  false if the defect correction stalls
+      auto gs = [&](const double shift, double* x, const double r1, const double* radd) {
+        cAe = 0.0;
+        for (int row = tid; row < S; row += nt) { dinv[row] = (row == 0) ? 1.0 : 1.0 / (loss[row] - shift); x[row] = 0.0; }
+        __syncthreads();
+        bool ok = false;
+        double ref = 0.0;                                               // correction size after 20 sweeps: the iteration must have shrunk it 30 sweeps later
+        for (int it = 0; it < 600; ++it) {
+          rhs_into(x, f, 0, nullptr);                                   // f = M_c x on the cube rows (x[0] = 0: no mRNA coupling)
+          for (int row = tid; row < S; row += nt)
+            res[row] = (row == 0) ? 0.0 : ((row == 1 ? r1 : 0.0) + (radd ? radd[row] : 0.0)) + f[row] + shift * x[row];
+          __syncthreads();
+          solve(res, dx);
+          double mdx = 0.0, mxx = 0.0;
+          for (int row = tid; row < S; row += nt) { const double xn = x[row] + dx[row]; x[row] = xn; mdx = fmax(mdx, fabs(dx[row])); mxx = fmax(mxx, fabs(xn)); }
+          mdx = wg_max(mdx, red); mxx = wg_max(mxx, red);
+          if (!(mdx == mdx) || !(mxx < 1e300)) break;
+          if (mdx <= 1e-14 * mxx + 1e-300) { ok = true; break; }
+          if (it == 20) ref = mdx;
+          if (it >= 50 && (it % 30) == 20) { if (mdx > 0.5 * ref) break; ref = mdx; }        // stalling or diverging (W_B indefinite: B beyond the cube's slowest rate)
+        }
+        __syncthreads();
+        return ok;
+      };
+      bool ok = gs(cB, uv, -cC * (cA - cB * R0), nullptr);            // W_B u = -C (A - B R0) e_0
+      if (ok) ok = gs(0.0, sv, cC * R0, uv);                           // W_0 s =  C R0 e_0 + u
+      if (ok) {
+        drift = true;
+        for (int row = tid; row < S; row += nt) y[row] = (row == 0) ? 0.0 : y[row] - sv[row];
+        __syncthreads();
+        set_p(0.0);
+        pofs = pv;
+        cAe = 0.0;
+      } else {
+        cAe = cA;
+      }
+    }
+  }
   double h;
   {
     rhs_into(y, f, 0, nullptr);
@@ -531,12 +602,20 @@ __global__ __launch_bounds__(256) void wide_rand_kernel(const SolveArgs A, doubl
         after_reject = false;
         if (last) {
           tc = te;
-          out.emit(k, y, false);
+          if (drift) {
+            set_p(tc - t0);
+            for (int row = tid; row < S; row += nt) Y[row] = y[row] + pv[row];
+            __syncthreads();
+            out.emit(k, Y, false);
+          } else {
+            out.emit(k, y, false);
+          }
           ++k;
           h = (hs < h) ? fmax(hnew, h) : hnew;
           if (k >= T) break;
           te = A.t[k];
         } else {
+          if (drift) set_p(tc - t0);
           h = hnew;
         }
       } else {
