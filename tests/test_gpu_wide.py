@@ -215,3 +215,45 @@ def test_randmod_n7_approximate_factorisation_path_still_in_band(golden_wide_fil
     """)
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "PK_WIDE_RAND_DENSE": "0"}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_ncube_kernel_drift_removal_bounds_the_steps_of_draws_that_never_rest(eng):
+    """randmod n = 8 (the n-cube kernel): mRNA degradation B ~ 0 -- down to exactly 0, where the mRNA grows linearly for ever -- used to cost
+    10-40x the steps of a benign draw.  With the closed-form response to the mRNA row subtracted the remainder comes to rest: step counts
+    stay in the benign range and the trajectories stay inside the band of the closed form."""
+    n, model = 8, pm.RAND
+    P, S = pm.n_params(model, n), pm.n_states(model, n)
+    rng = np.random.default_rng(20260515)
+    th = rng.uniform(0.0, 20.0, (12, P))
+    th[:5, 1] = (0.0, 1e-7, 0.0002, 0.008, 0.05)
+    t = pm.TIME_POINTS
+    r = eng.solve_ode_batch(model, th, np.ones(S), n, t, clip_nonneg=False)
+    ns, sol = _np(r.n_steps), _np(r.sol)
+    assert not _np(r.status).any()
+    assert ns[:, 0].max() <= 2500, ns[:, 0]
+    for b in range(6):
+        assert pm.band_error(sol[b], pm.solve_exact_lti(model, th[b], np.ones(S), n, t)) <= 0.6, b
+
+
+def test_ncube_kernel_without_drift_removal_still_in_band(golden_wide_files):
+    """PK_WIDE_RAND_DRIFT=0 (read once per process: a child process): the plain path on the reference fixture and on one slow-mRNA draw,
+    which then needs several times the steps."""
+    import os, subprocess, sys, textwrap
+    f = [x for x in golden_wide_files if x.name == "protein_randmod_n8_real.npz"]
+    f = f[0] if f else [x for x in golden_wide_files if "randmod_n8" in x.name][0]
+    code = textwrap.dedent(f"""
+        import numpy as np, sys
+        sys.path.insert(0, {str(pathlib.Path(__file__).resolve().parents[1])!r})
+        from phoskintime_amd import batch
+        from oracle import protein_models as pm
+        g = np.load({str(f)!r})
+        r = batch.solve_ode_batch("randmod", g["theta"][:3], g["y0"][:3], 8, g["t"], clip_nonneg=False)
+        e = pm.band_error(r.sol.cpu().numpy(), g["sol_tight"][:3])
+        assert not r.status.cpu().numpy().any() and e <= 0.6, e
+        th = np.random.default_rng(20260515).uniform(0.0, 20.0, (1, pm.n_params(2, 8))); th[0, 1] = 0.008
+        q = batch.solve_ode_batch("randmod", th, np.ones(257), 8, pm.TIME_POINTS, clip_nonneg=False)
+        print("ok", e, int(q.n_steps.cpu().numpy()[0, 0]))
+    """)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "PK_WIDE_RAND_DRIFT": "0"}, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+    assert int(out.stdout.split()[-1]) > 2500            # the same draw takes < 2 500 steps with the drift removed (test above)
