@@ -4,6 +4,7 @@
 #   network5  bench.py --only-network (BASELINE config 5 shape at rtol = atol = 1e-8): kernel stats + SQ counters of exactly that launch
 #   sens / sens_rand   the forward-sensitivity kernel (distmod n = 8, B = 65536 / randmod n = 4, B = 16384)
 #   rand7     randmod n = 7, B = 1024, theta ~ U(0, 20): the dense LRP12 kernel (pk_rand_dense.hpp)
+#   rand8     randmod n = 8, B = 1024, theta ~ U(0, 20): the n-cube kernel (additive Runge-Kutta, drift removal)
 #   tpr       the thread-per-replica kernel at BASELINE config 1 size (distmod n = 4, B = 524288): kernel stats + HBM / SQ counters
 set -u
 WHAT=${1:-config3}
@@ -20,6 +21,7 @@ case $WHAT in
   sens) CMD="python3 $REPO/tools/gpu_sens_one.py distmod 8 65536 10"; CMDS="python3 $REPO/tools/gpu_sens_one.py distmod 8 65536 2" ;;
   sens_rand) CMD="python3 $REPO/tools/gpu_sens_one.py randmod 4 16384 5"; CMDS="python3 $REPO/tools/gpu_sens_one.py randmod 4 16384 2" ;;
   rand7) CMD="python3 $REPO/tools/gpu_one.py 2 7 1024 10"; CMDS="python3 $REPO/tools/gpu_one.py 2 7 1024 2" ;;
+  rand8) CMD="python3 $REPO/tools/gpu_one.py 2 8 1024 5"; CMDS="python3 $REPO/tools/gpu_one.py 2 8 1024 2" ;;
   *) echo "unknown workload $WHAT"; exit 2 ;;
 esac
 cd /tmp
