@@ -257,3 +257,22 @@ def test_ncube_kernel_without_drift_removal_still_in_band(golden_wide_files):
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "PK_WIDE_RAND_DRIFT": "0"}, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
     assert int(out.stdout.split()[-1]) > 2500            # the same draw takes < 2 500 steps with the drift removed (test above)
+
+
+def test_ncube_kernel_drift_removal_declines_safely(eng):
+    """Draws where the two linear solves of the drift removal cannot be trusted -- mRNA degradation faster than the cube's slowest rate makes
+    M_c + B I indefinite (the defect correction stalls), or B is not small against the smallest loss rate -- are integrated as they stand:
+    still inside the band, never flagged."""
+    n, model = 8, pm.RAND
+    P, S = pm.n_params(model, n), pm.n_states(model, n)
+    rng = np.random.default_rng(4)
+    th = rng.uniform(0.5, 3.0, (3, P))
+    th[0, 3] = 1e-4; th[0, 4 + n:] = 1e-4; th[0, 1] = 0.02          # protein degradation ~ 1e-4 everywhere, mRNA degradation 0.02: indefinite
+    th[1, 1] = 15.0                                                  # B far above 0.25 x the smallest loss: not attempted
+    th[2, 1] = 0.0; th[2, 0] = 0.0                                   # no mRNA synthesis and no degradation: R constant, u = 0
+    t = pm.TIME_POINTS
+    r = eng.solve_ode_batch(model, th, np.ones(S), n, t, clip_nonneg=False)
+    assert not _np(r.status).any()
+    sol = _np(r.sol)
+    for b in range(3):
+        assert pm.band_error(sol[b], pm.solve_exact_lti(model, th[b], np.ones(S), n, t)) <= 0.6, b
