@@ -1,6 +1,5 @@
 // Instantiations + launcher of the random-model throughput kernel (pk_rand_fast.hpp).
 #include "pk_rand_fast.hpp"
-#include "pk_rand_fastr.hpp"
 #include <cstring>
 #include <cstdlib>
 #include "pk_launch.hpp"
@@ -17,29 +16,27 @@ static void launch_nb(const SolveArgs& a, int method, hipStream_t st) {
   else                          hipLaunchKernelGGL((rand_fast_kernel<NB, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), 0, st, a);
 }
 
-template <int NB, int RPL>
-static void launch_r(const SolveArgs& a, int method, hipStream_t st) {
-  constexpr int G = (1 << NB) / RPL;
-  const long long rpb = 256 / G;
-  const long long nblk = (a.B + rpb - 1) / rpb;
-  constexpr size_t lds = rand_fastr_lds_bytes<RPL>();
-  if (method == PK_METHOD_LRP12)     hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP12>), dim3((unsigned)nblk), dim3(256), lds, st, a);
-  else if (method == PK_METHOD_LRP8) hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_LRP8>), dim3((unsigned)nblk), dim3(256), lds, st, a);
-  else                               hipLaunchKernelGGL((rand_fastr_kernel<NB, RPL, PK_METHOD_RODAS4>), dim3((unsigned)nblk), dim3(256), lds, st, a);
-}
+// separate translation units (their unrolled Gauss-Jordan eliminations take minutes to compile: n = 6 one unit per method)
+void launch_rand_fastr(const SolveArgs& a, int method, hipStream_t st);        // n = 3, 4, 5: several bit-mask rows per lane (pk_rand_fastr.hpp)
+void launch_rand_fast6_lrp12(const SolveArgs& a, hipStream_t st);
+void launch_rand_fast6_lrp8(const SolveArgs& a, hipStream_t st);
+void launch_rand_fast6_rodas4(const SolveArgs& a, hipStream_t st);
 
 void launch_rand_fast(const SolveArgs& a, int method, hipStream_t st) {
   // dev A/B: PK_RAND_ROWS=1 keeps the one-row-per-lane kernels for n = 3, 4
   static const bool one_row = getenv("PK_RAND_ROWS") && !strcmp(getenv("PK_RAND_ROWS"), "1");
-  if (!one_row && a.n_sites == 3) { launch_r<3, 2>(a, method, st); return; }
-  if (!one_row && a.n_sites == 4) { launch_r<4, 4>(a, method, st); return; }
+  if (!one_row && (a.n_sites == 3 || a.n_sites == 4)) { launch_rand_fastr(a, method, st); return; }
   switch (a.n_sites) {
     case 1: launch_nb<1>(a, method, st); break;
     case 2: launch_nb<2>(a, method, st); break;
     case 3: launch_nb<3>(a, method, st); break;
     case 4: launch_nb<4>(a, method, st); break;
-    case 6: launch_nb<6>(a, method, st); break;            // 64 masks, one wave per replica, v_readlane broadcasts
-    default: launch_r<5, 2>(a, method, st); break;      // n = 5: two rows per lane, 16-lane groups (DPP broadcasts; one row per lane: 1.8x slower)
+    case 6:                                                // 64 masks, one wave per replica, v_readlane broadcasts
+      if (method == PK_METHOD_LRP12) launch_rand_fast6_lrp12(a, st);
+      else if (method == PK_METHOD_LRP8) launch_rand_fast6_lrp8(a, st);
+      else launch_rand_fast6_rodas4(a, st);
+      break;
+    default: launch_rand_fastr(a, method, st); break;     // n = 5: two rows per lane, 16-lane groups (DPP broadcasts; one row per lane: 1.8x slower)
   }
 }
 
