@@ -487,7 +487,7 @@ def secondary_legs(args, dev, tt, cpu):
         other = {}
         for label, mdl, nn, Bo in (("config1_size_distmod_n4_B65536", "distmod", 4, 65536), ("config2_succmod_n14_B4096", "succmod", 14, 4096),
                                    ("config2_size_succmod_n14_B65536", "succmod", 14, 65536), ("randmod_n4_B65536", "randmod", 4, 65536),
-                                   ("wide_distmod_n100_B4096", "distmod", 100, 4096), ("wide_succmod_n100_B4096", "succmod", 100, 4096), ("wide_randmod_n7_B1024", "randmod", 7, 1024), ("wide_randmod_n8_B256", "randmod", 8, 256)):
+                                   ("wide_distmod_n100_B4096", "distmod", 100, 4096), ("wide_succmod_n100_B4096", "succmod", 100, 4096), ("wide_randmod_n7_B1024", "randmod", 7, 1024), ("wide_randmod_n8_B1024", "randmod", 8, 1024)):
             Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
             tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.0, 20.0, (Bo, Po)), device=dev)
             oo = batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False)
