@@ -68,6 +68,11 @@ def test_no_cpu_fallback_without_gpu():
     import numpy as np
     with pytest.raises(PhoskinError):
         batch.solve_ode_batch(0, np.ones((1, 12)), np.ones(6), 4, [0.0, 1.0])
+    with pytest.raises(PhoskinError):
+        batch.solve_ode_sens_batch(0, np.ones((1, 12)), np.ones(6), 4, [0.0, 1.0])
+    from phoskintime_amd.models import distmod
+    with pytest.raises(PhoskinError):
+        distmod.solve_ode_jac(np.ones(12), np.ones(6), 4, [0.0, 1.0])
     src = "".join(p.read_text() for p in (ROOT / "phoskintime_amd").rglob("*.py"))
     assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", "")
 
