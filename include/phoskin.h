@@ -249,6 +249,10 @@ int pk_network_jacobian_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int 
  * All four topologies; combinatorial blocks (2) up to 3 sites per protein run out of registers, larger ones (<= 16 sites) in the LDS kernel. */
 int pk_network_simulate_batch(pk_ctx*, pk_net*, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
                               const double* t_host, int T, const pk_solver_opts* opts, double* Y, int32_t* status, int32_t* n_steps);
+/* The integrator pk_network_simulate_batch will run for `opts` (NULL = defaults) on this network: PK_METHOD_DP5, PK_METHOD_ARK436 or
+ * PK_METHOD_ROS34PW2; PK_ERR_UNSUPPORTED when ARK436 was requested and its kernel does not fit (N, sites per protein, 160 KB of LDS).  Pure
+ * host arithmetic.  Host layers derive integrator-dependent defaults (tolerances) from this answer instead of re-stating the rule. */
+int pk_network_resolve_method(const pk_net*, const pk_solver_opts* opts);
 /* global_model.params.unpack_params (softplus of the raw decision vectors): x_raw [B,n_var] -> x_phys [B,n_var]. */
 int pk_network_unpack_batch(pk_ctx*, pk_net*, int64_t B, const double* x_raw, double* x_phys);
 
@@ -281,6 +285,15 @@ void     pk_network_loss_destroy(pk_loss*);
 int      pk_network_objective_batch(pk_ctx*, pk_net*, pk_loss*, int64_t B, const double* Y, int T, int loss_mode,
                                     const double* x, int x_is_raw, const double* defaults, const double* lambdas, double fail_value,
                                     const int32_t* status, double* loss_sums, double* F);
+
+/* global_model.lossfn.LOSS_FN with its own positional argument list (lossfn.py:114-121; :386 picks loss_function_comb when MODEL == 2):
+ *   LOSS_FN(Y, p_prot, t_prot, obs_prot, w_prot, p_rna, t_rna, obs_rna, w_rna, p_pho, s_pho, t_pho, obs_pho, w_pho, prot_map,
+ *           prot_base_idx, rna_base_idx, pho_base_idx) -> (loss_p, loss_r, loss_ph)          [called at optproblem.py:137-145]
+ * for B trajectories and WITHOUT a network handle: the state offsets come from prot_map [N,2] int32 = (block start, n_sites) -- for the
+ * combinatorial topology (block start, n_states = 2^n_sites).  HOST pointers throughout (the reference passes numpy arrays): indices are
+ * checked on the host, arrays staged to HBM, one launch, synchronised.  Y [B,T,S]; loss_sums [B,3]; loss_mode = LOSS_MODE 0..7. */
+int pk_loss_fn_batch_host(pk_ctx*, int combinatorial, int loss_mode, int64_t B, const double* Y, int T, int S, const pk_loss_data*,
+                          const int32_t* prot_map, int N, double* loss_sums);
 
 /* Array form of the pred_fc columns of global_model.simulate.simulate_and_measure (simulate.py:119-202): fold changes for the index
  * lists of a pk_loss (protein | rna | phospho, obs / w ignored), floor eps (the reference uses 1e-12 there): pred [B, n_prot+n_rna+n_pho]. */

@@ -68,7 +68,7 @@ SYMBOLS = (
     "pk_time_solve_protein_batch", "pk_measure_hbm_gbs", "pk_measure_fp64_fma_tflops",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
-    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_observables_batch", "pk_frechet_batch",
+    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_observables_batch", "pk_frechet_batch", "pk_loss_fn_batch_host", "pk_network_resolve_method",
 )
 
 _lib = None
@@ -134,6 +134,9 @@ def load():
     lib.pk_network_objective_batch.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, i32, vp, vp, dbl, vp, vp, vp]
     lib.pk_network_observables_batch.restype = i32
     lib.pk_network_observables_batch.argtypes = [vp, vp, vp, i64, vp, i32, dbl, vp]
+    lib.pk_network_resolve_method.restype = i32; lib.pk_network_resolve_method.argtypes = [vp, optp]
+    lib.pk_loss_fn_batch_host.restype = i32
+    lib.pk_loss_fn_batch_host.argtypes = [vp, i32, i32, i64, vp, i32, i32, C.POINTER(LossData), vp, i32, vp]
     lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
     lib.pk_score_fit_batch.restype = i32; lib.pk_score_fit_batch.argtypes = [vp, i64, vp, i32, vp, vp, i32, vp, vp]
     lib.pk_measure_hbm_gbs.restype = dbl; lib.pk_measure_hbm_gbs.argtypes = [vp, i64, i32]

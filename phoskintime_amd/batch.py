@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence, Union
 
@@ -21,19 +22,23 @@ from ._capi import (DIST, SUCC, RAND, MODEL_IDS, METRICS, Context, PhoskinError,
 
 ArrayLike = Union[np.ndarray, torch.Tensor, Sequence[float]]
 
-_contexts: dict[int, Context] = {}
+_tls = threading.local()
 
 
 def get_context(device: Optional[int] = None) -> Context:
-    """Process-wide context for a GPU (created on first use).  Fails loudly when no GPU / library is present."""
+    """The calling THREAD's context for a GPU (created on first use, destroyed with the thread).  include/phoskin.h asks for one context
+    per thread: a context carries the stream of the last ``pk_set_stream`` and the staging buffers of the ``_host`` entry points, and
+    ctypes releases the GIL during calls, so two threads must never share one (the C side additionally serialises ``_host`` calls per
+    context).  Fails loudly when no GPU / library is present."""
     if not torch.cuda.is_available():
         # still go through load() first so that a missing .so is reported as such
         _capi.load()
         raise PhoskinError("phoskintime_amd needs a HIP GPU (torch.cuda.is_available() is False); there is no CPU fallback")
     dev = torch.cuda.current_device() if device is None else int(device)
-    ctx = _contexts.get(dev)
+    contexts = _tls.__dict__.setdefault("contexts", {})
+    ctx = contexts.get(dev)
     if ctx is None:
-        ctx = _contexts[dev] = Context(dev)
+        ctx = contexts[dev] = Context(dev)
     return ctx
 
 

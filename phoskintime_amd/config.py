@@ -8,6 +8,7 @@ explicit argument.
   TIME_POINTS / _RNA       config/constants.py:56-69
   Y_METRIC                 config/constants.py:104  ("total_signal")                        env PHOSKIN_Y_METRIC
   PERTURBATIONS_VALUE      config/constants.py:45   (config.toml:222 0.5)
+  USE_CUSTOM_WEIGHTS / USE_REGULARIZATION / ALPHA_CI      config/constants.py:52,74-75
 """
 import os
 import numpy as np
@@ -24,6 +25,18 @@ TIME_POINTS_RNA = np.array([4.0, 8.0, 15.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960
 
 # composite score weights, config/constants.py:77-83
 ALPHA_WEIGHT = BETA_WEIGHT = GAMMA_WEIGHT = DELTA_WEIGHT = MU_WEIGHT = 1.0
+
+# fit controls, config/constants.py:74-75 (config.toml:206-209), confidence level :52, output directory :141
+USE_CUSTOM_WEIGHTS = os.environ.get("PHOSKIN_USE_CUSTOM_WEIGHTS", "0").lower() in ("1", "true", "yes")
+USE_REGULARIZATION = os.environ.get("PHOSKIN_USE_REGULARIZATION", "1").lower() in ("1", "true", "yes")
+ALPHA_CI = 0.95
+SENSITIVITY_ANALYSIS = True
+#: where the drop-in callers write the files the reference writes (``<gene>_confidence_intervals.csv``, ``<gene>_parameters.xlsx``);
+#: None: nothing is written (the reference creates its results directory at import time)
+OUT_DIR = os.environ.get("PHOSKIN_OUT_DIR") or None
+#: measurement tables of models/weights.get_protein_weights (the reference hard-wires processing/input1_wstd.csv, data/input2.csv)
+INPUT1_WSTD_PATH = os.environ.get("PHOSKIN_INPUT1_WSTD", "processing/input1_wstd.csv")
+INPUT2_PATH = os.environ.get("PHOSKIN_INPUT2", "data/input2.csv")
 
 #: engine defaults for the single-call drop-ins (include/phoskin.h pk_default_opts)
 SOLVER_OPTS: dict = {}

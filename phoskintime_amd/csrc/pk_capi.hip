@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include "../../include/phoskin.h"
 #include "pk_launch.hpp"
@@ -23,6 +24,11 @@ struct pk_ctx {
   hipEvent_t ev0, ev1;
   pk_arena stage, scratch;                       // device memory
   void* pin = nullptr; size_t pin_bytes = 0; long long pin_allocs = 0;      // page-locked host staging for small calls
+  // The header asks for one context per thread, but a shared one must not corrupt memory: every `_host` entry point holds `mu` from
+  // staging to the final synchronisation (they share `stage` / `pin`), and launches that use `scratch` are ordered by `scratch_ev`
+  // across streams (pk_set_stream may change the stream between two calls).  Growing an arena drains the whole device first.
+  std::recursive_mutex mu;
+  hipEvent_t scratch_ev = nullptr; bool scratch_used = false;
 };
 
 namespace {
@@ -38,11 +44,12 @@ int fail(pk_ctx* c, int code, const std::string& msg) {
   } while (0)
 
 // Make `a` hold at least `bytes` (grow-only, 1.5x + 64 KB slack so that a slowly growing batch does not reallocate every call).
-// Growing frees the old buffer, so the stream is drained first: work queued by earlier calls may still read it.
+// Growing frees the old buffer, so the DEVICE is drained first: work queued by earlier calls -- on this stream or on one a caller set
+// before (pk_set_stream) -- may still read it.  Growth is rare (1.5x), so the device-wide wait costs nothing in steady state.
 int arena_reserve(pk_ctx* c, pk_arena& a, size_t bytes) {
   if (bytes <= a.bytes) return PK_OK;
   const size_t want = bytes + bytes / 2 + (64u << 10);
-  if (a.p) { PK_HIP(c, hipStreamSynchronize(c->stream)); PK_HIP(c, hipFree(a.p)); a.p = nullptr; a.bytes = 0; }
+  if (a.p) { PK_HIP(c, hipDeviceSynchronize()); PK_HIP(c, hipFree(a.p)); a.p = nullptr; a.bytes = 0; }
   hipError_t e = hipMalloc(&a.p, want);
   if (e != hipSuccess) { a.p = nullptr; return fail(c, PK_ERR_NOMEM, std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e)); }
   a.bytes = want; ++a.allocs;
@@ -51,7 +58,7 @@ int arena_reserve(pk_ctx* c, pk_arena& a, size_t bytes) {
 int pin_reserve(pk_ctx* c, size_t bytes) {
   if (bytes <= c->pin_bytes) return PK_OK;
   const size_t want = bytes + bytes / 2 + (64u << 10);
-  if (c->pin) { PK_HIP(c, hipStreamSynchronize(c->stream)); PK_HIP(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
+  if (c->pin) { PK_HIP(c, hipDeviceSynchronize()); PK_HIP(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
   hipError_t e = hipHostMalloc(&c->pin, want, hipHostMallocDefault);
   if (e != hipSuccess) { c->pin = nullptr; return fail(c, PK_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
   c->pin_bytes = want; ++c->pin_allocs;
@@ -135,7 +142,8 @@ pk_ctx* pk_create(int device_id) {
   c->device = device_id;
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return nullptr; }
   c->stream = c->own_stream;
-  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_create_err = "hipEventCreate failed"; delete c; return nullptr; }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming) != hipSuccess) { g_create_err = "hipEventCreate failed"; delete c; return nullptr; }
   return c;
 }
 
@@ -148,6 +156,7 @@ void pk_destroy(pk_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  if (c->scratch_ev) (void)hipEventDestroy(c->scratch_ev);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -223,11 +232,18 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
       }
       double* scr = nullptr;
       if (!pk::wide_rand_in_lds(n_sites)) {
+        // the scratch rows are shared by every launch of this context: reserve + launch under the lock, and order the launch after the
+        // previous scratch user whatever stream that one ran on
+        std::lock_guard<std::recursive_mutex> g(c->mu);
         rc = arena_reserve(c, c->scratch, pk::wide_rand_scratch_bytes(n_sites, B));
         if (rc) return rc;
         scr = (double*)c->scratch.p;
-      }
-      PK_HIP(c, pk::launch_wide_rand(a, scr, c->stream));
+        if (c->scratch_used) PK_HIP(c, hipStreamWaitEvent(c->stream, c->scratch_ev, 0));
+        PK_HIP(c, pk::launch_wide_rand(a, scr, c->stream));
+        PK_HIP(c, hipEventRecord(c->scratch_ev, c->stream));
+        c->scratch_used = true;
+      } else
+        PK_HIP(c, pk::launch_wide_rand(a, scr, c->stream));
     } else {
       if (o.method != PK_METHOD_LRP12 || o.stage_form)
         return fail(c, PK_ERR_UNSUPPORTED, "distmod / succmod with more than 64 states integrate with method LRP12 (the default) only");
@@ -413,6 +429,7 @@ int pk_solve_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, co
                                 int y0_is_batched, const double* t, int T, const pk_solver_opts* opts, double* sol,
                                 double* flat, double* metric, int metric_id, int32_t* status, int32_t* n_steps) {
   if (!c) return PK_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> host_guard(c->mu);          // `stage` / `pin` are shared by every `_host` call of this context
   int rc = check_model(c, model, n_sites);
   if (rc) return rc;
   if (B < 0 || T < 1) return fail(c, PK_ERR_ARG, "B must be >= 0 and T >= 1");
@@ -436,6 +453,7 @@ int pk_solve_protein_sens_batch_host(pk_ctx* c, int model, int n_sites, int64_t 
                                      const double* t, int T, const pk_solver_opts* opts, double* flat, double* dflat, int32_t* status,
                                      int32_t* n_steps) {
   if (!c) return PK_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> host_guard(c->mu);          // `stage` / `pin` are shared by every `_host` call of this context
   int rc = check_model(c, model, n_sites);
   if (rc) return rc;
   if (B < 0 || T < 1) return fail(c, PK_ERR_ARG, "B must be >= 0 and T >= 1");
@@ -459,6 +477,7 @@ int pk_solve_protein_sens_batch_host(pk_ctx* c, int model, int n_sites, int64_t 
 
 int pk_rhs_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, const double* y, double* dydt) {
   if (!c) return PK_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> host_guard(c->mu);          // `stage` / `pin` are shared by every `_host` call of this context
   int rc = check_model(c, model, n_sites);
   if (rc) return rc;
   if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
@@ -476,6 +495,7 @@ int pk_rhs_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, cons
 
 int pk_jacobian_protein_batch_host(pk_ctx* c, int model, int n_sites, int64_t B, const double* theta, double* J) {
   if (!c) return PK_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> host_guard(c->mu);          // `stage` / `pin` are shared by every `_host` call of this context
   int rc = check_model(c, model, n_sites);
   if (rc) return rc;
   if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 #include "../../include/phoskin.h"
 #include "pk_network.hpp"
@@ -97,6 +98,7 @@ struct pk_net {
   int nnzT = 0;
   std::vector<double> kin_grid_host;
   double* stops_dev = nullptr; int32_t* stop_out_dev = nullptr; size_t stops_cap = 0;
+  std::mutex mu;       // a network handle may be shared by the threads of a process (each with its own pk_ctx): guards the stop buffers
 };
 
 namespace {
@@ -219,6 +221,21 @@ int pk_network_jacobian_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
 }
 
+// Which integrator pk_network_simulate_batch runs for these options on this network -- the single source of truth (the Python host layer
+// picks its default tolerances from it).  PK_METHOD_DP5 on request; PK_METHOD_ARK436 where its kernel fits and is the default (or was
+// asked for); otherwise PK_METHOD_ROS34PW2.  PK_ERR_UNSUPPORTED when ARK436 was requested and cannot run.
+int pk_network_resolve_method(const pk_net* n, const pk_solver_opts* opts) {
+  if (!n) return PK_ERR_ARG;
+  const int method = opts ? opts->method : PK_METHOD_LRP12, linsolve = opts ? opts->linsolve : PK_LINSOLVE_AUTO;
+  if (method == PK_METHOD_DP5) return PK_METHOD_DP5;
+  const int threads_a = ((n->d.N + 63) / 64) * 64;
+  const bool ark_fits = n->d.N <= 256 && n->max_sites <= (n->d.model == 2 ? 3 : 8) && linsolve != PK_LINSOLVE_STRUCTURED;
+  const bool ark_ok = ark_fits && pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) <= 160 * 1024;
+  if (method == PK_METHOD_ARK436) return ark_ok ? PK_METHOD_ARK436 : PK_ERR_UNSUPPORTED;
+  // combinatorial topology: the additive kernel exists (on request) but its step costs 2.8x a Rosenbrock-W step there: order 3 by default
+  return (ark_ok && n->d.model != 2 && method != PK_METHOD_ROS34PW2) ? PK_METHOD_ARK436 : PK_METHOD_ROS34PW2;
+}
+
 int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
                               const double* t_host, int T, const pk_solver_opts* opts_in, double* Y, int32_t* status, int32_t* n_steps) {
   if (!c || !n) return PK_ERR_ARG;
@@ -268,7 +285,8 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
     for (size_t i = 0; i < st.size(); ++i) { a.stops_v[i] = st[i].first; a.stop_out_v[i] = st[i].second; }
   } else {
     // long output grids: stage through a per-network device buffer (the previous launch on it must have finished)
-    if (hipStreamSynchronize(stream) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipStreamSynchronize");
+    std::lock_guard<std::mutex> g(n->mu);
+    if (hipDeviceSynchronize() != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipDeviceSynchronize");      // any stream of any context
     if (n->stops_cap < st.size()) {
       if (n->stops_dev) (void)hipFree(n->stops_dev);
       if (n->stop_out_dev) (void)hipFree(n->stop_out_dev);
@@ -301,16 +319,11 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   // ---- default integrator: ARK436 (order 4) in the one-thread-per-protein layout; ROS34PW2 (order 3) everywhere else / on request
   {
     const int threads_a = ((n->d.N + 63) / 64) * 64;
-    const bool ark_fits = n->d.N <= 256 && n->max_sites <= (n->d.model == 2 ? 3 : 8) && o.linsolve != PK_LINSOLVE_STRUCTURED;
-    const size_t lds_a = ark_fits ? pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) : 0;
-    const bool ark_ok = ark_fits && lds_a <= 160 * 1024;
-    if (o.method == PK_METHOD_ARK436 && !ark_ok)
+    const int resolved = pk_network_resolve_method(n, &o);
+    if (resolved == PK_ERR_UNSUPPORTED)
       return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "PK_METHOD_ARK436: N <= 256 and <= 8 sites per protein (combinatorial topology: <= 3); use PK_METHOD_ROS34PW2");
-    // combinatorial topology: the additive kernel exists (PK_METHOD_ARK436 on request) and takes 2.4-2.7x fewer steps, but its step costs
-    // 2.8x a Rosenbrock-W step there (nine rows per thread: spills, the extra product with P, LDS parking): 18.3 k vs 20.9 k candidates/s
-    // at 1e-8 on the S = 900 population -- so the order-3 kernel stays the default for topology 2
-    const bool ark_default = ark_ok && n->d.model != 2;
-    if ((ark_default && o.method != PK_METHOD_ROS34PW2) || (ark_ok && o.method == PK_METHOD_ARK436)) {
+    const size_t lds_a = resolved == PK_METHOD_ARK436 ? pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) : 0;
+    if (resolved == PK_METHOD_ARK436) {
       // The order-4 method runs at 0.25 x the requested tolerances: at that factor its error equals the order-3 method's at the SAME nominal
       // tolerance.  Measured at rtol = atol = 1e-8, band widths from the converged solution (tools/gpu_ark_population*.py, bench.py):
       //   BASELINE config 5's population (8 192 candidates, log-normal 0.5 around the defaults), fixture candidate vs LSODA@1e-12:

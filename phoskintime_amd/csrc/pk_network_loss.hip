@@ -159,6 +159,45 @@ __global__ __launch_bounds__(256) void net_observables_kernel(const NetDev n, co
   }
 }
 
+// LOSS_FN without a network handle: the state offsets come from the caller's prot_map [N, 2] = (block start, n_sites | n_states), exactly
+// the table global_model.lossfn.loss_function_noncomb / _comb index (lossfn.py:114-121, 250-257).  One workgroup per trajectory.
+__global__ __launch_bounds__(256) void loss_fn_kernel(const LossDev L, const int32_t* __restrict__ prot_map, const int comb,
+                                                      const double* __restrict__ Y, const int T, const int S, const int mode,
+                                                      double* __restrict__ sums) {
+  __shared__ double red[8];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const double* Yb = Y + b * (size_t)T * S;
+  auto at = [&](int t, int s) { return Yb[(size_t)t * S + s]; };
+  double lp = 0.0, lr = 0.0, lph = 0.0;
+  for (int k = tid; k < L.n_prot; k += nt) {
+    const int i = L.p_prot[k], st = prot_map[2 * i], t = L.t_prot[k];
+    const int cnt = comb ? prot_map[2 * i + 1] : 1 + prot_map[2 * i + 1];          // all 2^n states | P + its n site states
+    double tt = 0.0, tb = 0.0;
+    for (int m = 0; m < cnt; ++m) { tt += at(t, st + 1 + m); tb += at(L.base_prot, st + 1 + m); }
+    const double pred = fold_change(tt, tb);
+    lp += L.w_prot[k] * point_loss(mode, L.obs_prot[k] - pred, L.obs_prot[k], pred);
+  }
+  for (int k = tid; k < L.n_rna; k += nt) {
+    const int st = prot_map[2 * L.p_rna[k]];
+    const double pred = fold_change(at(L.t_rna[k], st), at(L.base_rna, st));
+    lr += L.w_rna[k] * point_loss(mode, L.obs_rna[k] - pred, L.obs_rna[k], pred);
+  }
+  for (int k = tid; k < L.n_pho; k += nt) {
+    const int i = L.p_pho[k], st = prot_map[2 * i], t = L.t_pho[k], j = L.s_pho[k];
+    double a, c;
+    if (comb) {
+      a = 0.0; c = 0.0;
+      const int cnt = prot_map[2 * i + 1];
+      for (int m = 0; m < cnt; ++m) if (m & (1 << j)) { a += at(t, st + 1 + m); c += at(L.base_pho, st + 1 + m); }
+    } else { a = at(t, st + 2 + j); c = at(L.base_pho, st + 2 + j); }
+    const double pred = fold_change(a, c);
+    lph += L.w_pho[k] * point_loss(mode, L.obs_pho[k] - pred, L.obs_pho[k], pred);
+  }
+  lp = block_sum(lp, red); lr = block_sum(lr, red); lph = block_sum(lph, red);
+  if (tid == 0) { sums[3 * b] = lp; sums[3 * b + 1] = lr; sums[3 * b + 2] = lph; }
+}
+
 }  // namespace pk
 
 struct pk_loss {
@@ -252,6 +291,64 @@ int pk_network_observables_batch(pk_ctx* c, pk_net* net, pk_loss* l, int64_t B, 
   hipLaunchKernelGGL(pk::net_observables_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)pk_ctx_stream(c), *pk_net_dev(net), l->d, Y, T, eps, pred);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+// LOSS_FN(Y, p_prot, t_prot, obs_prot, w_prot, p_rna, ..., w_pho, prot_map, prot_base_idx, rna_base_idx, pho_base_idx) for B trajectories,
+// host pointers throughout (the reference's call shape: numpy arrays): index-checked on the host, staged to HBM, one launch, synchronised.
+int pk_loss_fn_batch_host(pk_ctx* c, int combinatorial, int loss_mode, int64_t B, const double* Y, int T, int S, const pk_loss_data* d,
+                          const int32_t* prot_map, int N, double* loss_sums) {
+  if (!c) return PK_ERR_ARG;
+  if (B < 0 || T < 1 || S < 1 || N < 0) return pk_ctx_fail(c, PK_ERR_ARG, "B >= 0, T >= 1, S >= 1, N >= 0 required");
+  if (B == 0) return PK_OK;
+  if (!Y || !d || !loss_sums || (N && !prot_map)) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
+  if (d->n_prot < 0 || d->n_rna < 0 || d->n_pho < 0) return pk_ctx_fail(c, PK_ERR_ARG, "bad loss-data sizes");
+  auto bad_t = [&](int t) { return t < 0 || t >= T; };
+  if (bad_t(d->prot_base_idx) || bad_t(d->rna_base_idx) || bad_t(d->pho_base_idx)) return pk_ctx_fail(c, PK_ERR_ARG, "baseline index outside the time grid");
+  // every state index the kernel will form must lie inside a trajectory row
+  auto blk_ok = [&](int i) {
+    if (i < 0 || i >= N) return false;
+    const int st = prot_map[2 * i], cnt = prot_map[2 * i + 1];
+    if (st < 0 || cnt < 0 || (combinatorial && cnt > (1 << 20))) return false;
+    return (long long)st + 1 + (combinatorial ? cnt : 1 + cnt) <= (long long)S;
+  };
+  for (int k = 0; k < d->n_prot; ++k) if (!blk_ok(d->p_prot[k]) || bad_t(d->t_prot[k])) return pk_ctx_fail(c, PK_ERR_ARG, "protein observation index out of range");
+  for (int k = 0; k < d->n_rna; ++k) if (!blk_ok(d->p_rna[k]) || bad_t(d->t_rna[k])) return pk_ctx_fail(c, PK_ERR_ARG, "rna observation index out of range");
+  for (int k = 0; k < d->n_pho; ++k) {
+    if (!blk_ok(d->p_pho[k]) || bad_t(d->t_pho[k]) || d->s_pho[k] < 0) return pk_ctx_fail(c, PK_ERR_ARG, "phospho observation index out of range");
+    const int cnt = prot_map[2 * d->p_pho[k] + 1];
+    if (combinatorial ? (d->s_pho[k] >= 20 || (1 << d->s_pho[k]) >= (cnt > 1 ? cnt : 1)) : d->s_pho[k] >= cnt)
+      return pk_ctx_fail(c, PK_ERR_ARG, "phospho site index out of range");
+  }
+  if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
+  pk_loss tmp;
+  bool ok = true;
+  pk::LossDev& v = tmp.d;
+  v.n_prot = d->n_prot; v.n_rna = d->n_rna; v.n_pho = d->n_pho;
+  v.base_prot = d->prot_base_idx; v.base_rna = d->rna_base_idx; v.base_pho = d->pho_base_idx;
+  v.p_prot = up(&tmp, d->p_prot, d->n_prot, ok); v.t_prot = up(&tmp, d->t_prot, d->n_prot, ok);
+  v.obs_prot = up(&tmp, d->obs_prot, d->n_prot, ok); v.w_prot = up(&tmp, d->w_prot, d->n_prot, ok);
+  v.p_rna = up(&tmp, d->p_rna, d->n_rna, ok); v.t_rna = up(&tmp, d->t_rna, d->n_rna, ok);
+  v.obs_rna = up(&tmp, d->obs_rna, d->n_rna, ok); v.w_rna = up(&tmp, d->w_rna, d->n_rna, ok);
+  v.p_pho = up(&tmp, d->p_pho, d->n_pho, ok); v.s_pho = up(&tmp, d->s_pho, d->n_pho, ok); v.t_pho = up(&tmp, d->t_pho, d->n_pho, ok);
+  v.obs_pho = up(&tmp, d->obs_pho, d->n_pho, ok); v.w_pho = up(&tmp, d->w_pho, d->n_pho, ok);
+  v.norm_p = v.norm_r = v.norm_ph = 1.0;
+  const int32_t* pm = up(&tmp, prot_map, (size_t)2 * N, ok);
+  const double* Yd = up(&tmp, Y, (size_t)B * T * S, ok);
+  double* out = nullptr;
+  if (ok && hipMalloc((void**)&out, (size_t)B * 3 * sizeof(double)) == hipSuccess) tmp.allocs.push_back(out); else ok = false;
+  int rc = PK_OK;
+  if (!ok) rc = pk_ctx_fail(c, PK_ERR_NOMEM, "hipMalloc / hipMemcpy failed");
+  else {
+    hipStream_t st = (hipStream_t)pk_ctx_stream(c);
+    hipLaunchKernelGGL(pk::loss_fn_kernel, dim3((unsigned)B), dim3(256), 0, st, v, pm, combinatorial ? 1 : 0, Yd, T, S, loss_mode, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(loss_sums, out, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+  }
+  for (void* p : tmp.allocs) (void)hipFree(p);
+  return rc;
 }
 
 }  // extern "C"

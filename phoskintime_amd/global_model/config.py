@@ -17,6 +17,8 @@ SENSITIVITY_TRAJECTORIES = 100
 SENSITIVITY_LEVELS = 40
 SENSITIVITY_TOP_CURVES = 20
 SENSITIVITY_METRIC = "total_signal"
+SEED = 42              # config.toml [global_model] seed (global_model/config.py)
+LOSS_MODE = int(os.environ.get("PHOSKIN_LOSS_MODE", "0"))   # config.toml [global_model.loss] mode (global_model/config.py); 0 = squared error
 # physical parameter bounds of the optimiser (config.toml:368-397 [global_model.bounds])
 BOUNDS_CONFIG = {"c_k": (1e-3, 4.0), "A_i": (1e-6, 10.0), "B_i": (1e-3, 1.0), "C_i": (1e-3, 2.0), "D_i": (0.1, 0.5), "Dp_i": (0.05, 5.0),
                  "E_i": (1e-4, 10.0), "tf_scale": (2.0, 10.0)}

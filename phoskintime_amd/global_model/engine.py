@@ -26,7 +26,7 @@ class NetworkEngine:
 
     def __init__(self, model: int, offset_y, offset_s, n_sites, W_indptr, W_indices, W_data, TF_indptr, TF_indices, TF_data,
                  tf_deg, driver_map, kin_grid, kin_Kmat, device: Optional[int] = None):
-        self.ctx = get_context(device)
+        self._device = get_context(device).device
         self.model = int(model)
         self._keep = [_i32(offset_y), _i32(offset_s), _i32(n_sites), _i32(W_indptr), _i32(W_indices), _f64(W_data),
                       _i32(TF_indptr), _i32(TF_indices), _f64(TF_data), _f64(tf_deg), _i32(driver_map), _f64(kin_grid), _f64(kin_Kmat)]
@@ -41,6 +41,12 @@ class NetworkEngine:
             raise _capi.PhoskinError("pk_network_create failed: " + (self.ctx.lib.pk_last_error(self.ctx.handle) or b"").decode())
         self.S = self.ctx.lib.pk_network_n_states(self._h)
         self.n_var = self.ctx.lib.pk_network_n_var(self._h)
+
+    @property
+    def ctx(self):
+        """The CALLING thread's context on this engine's GPU (``batch.get_context``): the network handle is read-only device data and may
+        be used from any thread, the context (stream, staging buffers, last error) may not be shared."""
+        return get_context(self._device)
 
     # ------------------------------------------------------------------ constructors from reference objects
     @staticmethod
@@ -80,7 +86,7 @@ class NetworkEngine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.ctx.lib.pk_network_destroy(self._h)
+            _capi.load().pk_network_destroy(self._h)
             self._h = None
 
     def __del__(self):  # pragma: no cover
@@ -146,14 +152,15 @@ class NetworkEngine:
         (tools/gpu_norm_scan.py): on the reference-run fixtures the RMS run at 1e-8 / 1e-8 lands 0.04-0.27 band widths from LSODA at 1e-12
         (the reference's own LSODA run at those settings: 0.05-0.43), but on random full-size combinatorial populations it reaches 2 band
         widths and at 1e-5 / 1e-7 it is 6x less accurate than LSODA -- the order-3 method's error constant is larger.  Hence opt-in."""
-        if rtol is None or atol is None:
-            # parity-grade defaults (worst band error over every reference-run fixture <= 0.3, tools/gpu_norm_scan.py): the order-4 method
-            # at the reference optimiser's own tolerances (config.toml:403-404), the order-3 method at 1e-7 / 1e-9
-            ark = (self.ark_eligible() and method == "auto" or method == "ark") and kernel != "lds"
-            rtol = (1e-8 if ark else 1e-7) if rtol is None else rtol
-            atol = (1e-8 if ark else 1e-9) if atol is None else atol
         if method not in ("auto", "ark", "rosw", "dp5"):
             raise ValueError("method must be 'auto', 'ark', 'rosw' or 'dp5'")
+        if rtol is None or atol is None:
+            # parity-grade defaults (worst band error over every reference-run fixture <= 0.3, tools/gpu_norm_scan.py): the order-4 method
+            # at the reference optimiser's own tolerances (config.toml:403-404), the order-3 method at 1e-7 / 1e-9.  Which of the two
+            # will run is the library's decision (pk_network_resolve_method), not restated here
+            ark = self.resolved_method(method, kernel) == "ark"
+            rtol = (1e-8 if ark else 1e-7) if rtol is None else rtol
+            atol = (1e-8 if ark else 1e-9) if atol is None else atol
         dev = torch.device("cuda", self.ctx.device)
         xd = _dev_f64(x, dev)
         if xd.dim() == 1:
@@ -182,11 +189,19 @@ class NetworkEngine:
         Y._keepalive = (xd, yd)  # type: ignore[attr-defined]
         return Y, status, nsteps
 
+    def resolved_method(self, method: str = "auto", kernel: str = "auto") -> str:
+        """The integrator ``simulate_batch(method=, kernel=)`` will run on this network -- "ark", "rosw" or "dp5" -- as decided by the
+        library itself (``pk_network_resolve_method``: network size, sites per protein AND the LDS footprint of the order-4 kernel).
+        Raises PhoskinError when "ark" was requested and cannot run."""
+        opts = _capi.default_opts(linsolve=("structured" if kernel == "lds" else "auto"), method={"dp5": "dp5", "ark": "ark436", "rosw": "ros34pw2"}.get(method))
+        m = _capi.load().pk_network_resolve_method(self._h, C.byref(opts))
+        if m < 0:
+            raise _capi.PhoskinError("method='ark': the order-4 kernel does not fit this network (N <= 256, <= 8 sites per protein, 160 KB of LDS)")
+        return {_capi.METHOD_DP5: "dp5", _capi.METHOD_ARK436: "ark"}.get(m, "rosw")
+
     def ark_eligible(self) -> bool:
-        """Whether pk_network_simulate_batch runs the order-4 additive integrator on this network BY DEFAULT (one thread per protein:
-        topologies 0 / 1 / 4, N <= 256, at most 8 sites per protein).  The combinatorial topology has the kernel too (method="ark",
-        <= 3 sites) but its order-3 kernel is faster per result, so it is not the default there."""
-        return self.model != 2 and self.N <= 256 and (int(self._keep[2].max()) if self.N else 0) <= 8
+        """Whether pk_network_simulate_batch runs the order-4 additive integrator on this network BY DEFAULT."""
+        return self.resolved_method() == "ark"
 
     # ------------------------------------------------------------------ loss / objectives
     def make_loss(self, loss_data: dict, T: int):

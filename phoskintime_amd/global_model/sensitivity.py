@@ -76,15 +76,29 @@ def scalar_metric_batch(pred: torch.Tensor, metric: str = "total_signal") -> tor
 def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, times_r, times_ph, perturbation: float = config.SENSITIVITY_PERTURBATION,
                           trajectories: int = config.SENSITIVITY_TRAJECTORIES, num_levels: int = config.SENSITIVITY_LEVELS,
                           metric: str = config.SENSITIVITY_METRIC, seed: Optional[int] = None,
-                          param_values: Optional[np.ndarray] = None, y0=None, conf_level: float = 0.95, rtol: Optional[float] = None, atol: Optional[float] = None):
+                          param_values: Optional[np.ndarray] = None, y0=None, conf_level: float = 0.95, rtol: Optional[float] = None, atol: Optional[float] = None,
+                          vary=None, return_pred: bool = False):
     """Returns dict(Si, problem, param_values, Y, status).  ``fitted_params`` maps the eight parameter groups (System.update order)
-    to arrays / a scalar; every entry is varied, as in the reference (sensitivity.py:196-215)."""
+    to arrays / a scalar; every entry is varied, as in the reference (sensitivity.py:196-215) -- unless ``vary`` names a subset: indices
+    into the flat parameter vector (or parameter names ``"A_i_3"``, ``"tf_scale"``); the design then has len(vary) dimensions
+    (trajectories x (len(vary) + 1) simulations: BASELINE config 4 is 128 x (200 + 1)) and every other entry stays at its fitted value.
+    ``param_values`` (a ready sample matrix) has one column per varied entry.  ``return_pred``: also return the fold-change observables
+    ``pred`` [rows of this rank, n_obs] (GPU tensor) and their ``layout``."""
     params = {k: (np.asarray(fitted_params[k], float) if k != "tf_scale" else float(fitted_params[k])) for k in _ORDER}
     from .simulate import measure_tolerances                  # the settings of simulate_and_measure, which the reference's workers call
     tol = measure_tolerances(eng)
     rtol = tol["rtol"] if rtol is None else rtol
     atol = tol["atol"] if atol is None else atol
     problem = compute_bounds(params, perturbation)
+    center = None
+    if vary is not None:
+        names = problem["names"]
+        pos = {nm: i for i, nm in enumerate(names)}
+        vidx = np.array([pos[v] if isinstance(v, str) else int(v) for v in vary], dtype=np.int64)
+        if vidx.size == 0 or np.unique(vidx).size != vidx.size or vidx.min() < 0 or vidx.max() >= len(names):
+            raise ValueError("vary must hold distinct indices (or names) of the flat parameter vector")
+        center = eng.pack_params(*(params[k] for k in _ORDER))
+        problem = {"num_vars": int(vidx.size), "names": [names[i] for i in vidx], "bounds": [problem["bounds"][i] for i in vidx]}
     design = None
     seed = shared_seed(seed)              # N > 1 ranks: every rank must build the SAME design (seed=None would give each its own)
     if param_values is None:
@@ -92,6 +106,12 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
         Xd, design = morris.sample_device(problem, N=trajectories, num_levels=num_levels, seed=seed, device=eng.ctx.device)
     else:
         Xd = torch.as_tensor(np.ascontiguousarray(param_values, dtype=np.float64), device=torch.device("cuda", eng.ctx.device))
+    if Xd.shape[1] != problem["num_vars"]:
+        raise ValueError(f"the sample matrix has {Xd.shape[1]} columns, the problem {problem['num_vars']} variables")
+    Xv = Xd                                                             # the design in its own (varied) coordinates
+    if center is not None:                                              # scatter the varied columns into copies of the fitted vector (in HBM)
+        Xd = torch.as_tensor(center, device=Xv.device).repeat(Xv.shape[0], 1)
+        Xd[:, torch.as_tensor(vidx, device=Xv.device)] = Xv
     if Xd.shape[1] != eng.n_var:                                        # flat vector order == candidate row order (both System.update order)
         raise ValueError(f"parameter vector has {Xd.shape[1]} entries, the network expects {eng.n_var}")
     total = Xd.shape[0]
@@ -101,6 +121,7 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
     lo, hi = shard_bounds(total, rank, world)
     lists, ld = eng.make_index_lists(times, times_p, times_r, times_ph)
     n_obs = ld["p_prot"].size + ld["p_rna"].size + ld["p_pho"].size
+    pred = None
     try:
         if hi > lo:
             Y, status, _ = eng.simulate_batch(Xd[lo:hi], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
@@ -118,9 +139,57 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
     finally:
         eng.free_loss(lists)
     Yh = Yall.cpu().numpy()
-    X = Xd.cpu().numpy()
+    X = Xv.cpu().numpy()
     if design is not None:
         Si = morris.analyze_effects(ee, problem.get("names"), conf_level=conf_level, seed=seed)
     else:
         Si = morris.analyze(problem, X, Yh, num_levels=num_levels, conf_level=conf_level, seed=seed)
-    return {"Si": Si, "problem": problem, "param_values": X, "Y": Yh, "status": stat.cpu().numpy()}
+    out = {"Si": Si, "problem": problem, "param_values": X, "Y": Yh, "status": stat.cpu().numpy()}
+    if return_pred:
+        out.update(pred=pred, layout=ld, rows=(lo, hi), times=times)
+    return out
+
+
+def _worker_simulation(task_args):
+    """``(idx, param_vector, names_map, original_shapes, sys, idx_sys, times_p, times_r, times_ph, metric) -> (idx, y, dfp, dfr, dfph)``:
+    the reference's pool worker (sensitivity.py:143-168), one simulation.  ``run_sensitivity_analysis`` does not use it: all samples are
+    one launch and no ``System`` is pickled."""
+    from .simulate import simulate_and_measure
+    (i, param_vector, names_map, original_shapes, sys, idx_sys, times_p, times_r, times_ph, metric) = task_args
+    sys.update(**_reconstruct_params(param_vector, names_map, original_shapes))
+    dfp, dfr, dfph = simulate_and_measure(sys, idx_sys, times_p, times_r, times_ph)
+    return i, _compute_scalar_metric(dfp, dfr, dfph, metric), dfp, dfr, dfph
+
+
+def run_sensitivity_analysis(sys, idx, fitted_params, output_dir, metric="total_signal", seed: Optional[int] = None,
+                             param_values: Optional[np.ndarray] = None):
+    """Morris screening of the network around ``fitted_params`` with the reference's argument list (sensitivity.py:171-297) -> the
+    DataFrame ``Parameter, mu_star, sigma, mu_star_conf`` sorted by influence, also written to ``<output_dir>/sensitivity_indices.csv``.
+
+    N = ``config.SENSITIVITY_TRAJECTORIES`` trajectories on ``config.SENSITIVITY_LEVELS`` levels within +-``config.SENSITIVITY_PERTURBATION``
+    of every entry; the N (D + 1) simulations are ONE launch on the engine of ``sys`` (the reference pickles the whole System into every
+    task of a process pool); under an initialised ``torch.distributed`` group the rows are sharded over the ranks with one all-gather of Y.
+    ``<output_dir>/sensitivity_trajectories.csv`` lists the ``config.SENSITIVITY_TOP_CURVES`` samples of largest Y (id, y_val and the
+    sampled parameter values; the reference stores whole DataFrames in that table's cells).  The two plots (:290-296) are not drawn.
+    ``seed`` defaults to ``config.SEED``; ``param_values`` (keyword, not in the reference) takes a ready sample matrix such as SALib's."""
+    import os
+    import pandas as pd
+    from .simulate import engine_for
+    eng = engine_for(sys)
+    params = {}
+    for k in _ORDER:
+        v = fitted_params[k]
+        params[k] = float(v) if k == "tf_scale" else np.asarray(v, dtype=float)
+    res = run_sensitivity_batch(eng, params, config.TIME_POINTS_PROTEIN, config.TIME_POINTS_RNA, config.TIME_POINTS_PHOSPHO, metric=metric,
+                                seed=config.SEED if seed is None else seed, param_values=param_values, y0=np.asarray(sys.y0(), dtype=np.float64))
+    Si = res["Si"]
+    df_sens = pd.DataFrame({"Parameter": res["problem"]["names"], "mu_star": Si["mu_star"], "sigma": Si["sigma"], "mu_star_conf": Si["mu_star_conf"]})
+    df_sens = df_sens.sort_values("mu_star", ascending=False)
+    if output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+        df_sens.to_csv(os.path.join(output_dir, "sensitivity_indices.csv"), index=False)
+        top = np.argsort(-res["Y"], kind="stable")[:config.SENSITIVITY_TOP_CURVES]
+        traj = pd.DataFrame(res["param_values"][top], columns=res["problem"]["names"])
+        traj.insert(0, "y_val", res["Y"][top]); traj.insert(0, "id", top)
+        traj.to_csv(os.path.join(output_dir, "sensitivity_trajectories.csv"), index=False)
+    return df_sens

@@ -16,16 +16,14 @@ from . import config
 from .engine import NetworkEngine
 
 # id(sys) -> (weakref to sys, {model: engine}).  The weak reference is what makes the id trustworthy: an entry is used only while its
-# referent is alive AND identical to the caller's object, and a finalizer closes the engines (frees their HBM) when the System dies, so
-# a recycled id can never hand out a stale topology.
+# referent is alive AND identical to the caller's object, and a finalizer drops the entry when the System dies, so a recycled id can
+# never hand out a stale topology.  Eviction only forgets the engines: a caller may still hold one (``eng = engine_for(build_system())``),
+# and the HBM of an engine is freed when ITS last reference dies (NetworkEngine.__del__).
 _engines: dict = {}
 
 
 def _evict(key: int) -> None:
-    ent = _engines.pop(key, None)
-    if ent is not None:
-        for eng in ent[1].values():
-            eng.close()
+    _engines.pop(key, None)
 
 
 def engine_for(sys, model=None) -> NetworkEngine:

@@ -15,6 +15,11 @@ def _bind(name: str):
     return importlib.import_module(f"{__name__}.{name}")
 
 
+def model_module_for(name: str):
+    """The drop-in module of one model by name, whatever ``solve_ode`` is currently bound to."""
+    return _bind(name)
+
+
 model_module = _bind(config.ODE_MODEL)
 solve_ode = model_module.solve_ode
 solve_ode_jac = model_module.solve_ode_jac          # not in the reference: flat and its parameter Jacobian from one integration

@@ -71,7 +71,7 @@ class RowsFit:
 
 def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None,
                    max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra="auto", jacobian="auto", trial_levels="auto",
-                   **solver_kw) -> RowsFit:
+                   force_reg: Optional[bool] = None, **solver_kw) -> RowsFit:
     """R independent bounded least-squares problems in lockstep: row k fits ``[flat(p) ; lam_k / P * p**2]`` to ``[target_k ; 0]`` with
     weights ``sigma_k`` from the start point ``P0[k]``.  Rows may be the starts of one multistart fit, the (lambda, weight) grid of
     ``find_best_lambda``, bootstrap replicates, different proteins of the same size -- or any mix.
@@ -102,7 +102,9 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     tgt = np.broadcast_to(target, (R, target.shape[-1])) if target.ndim == 1 else target
     Nd = tgt.shape[1]
     lam = np.broadcast_to(np.asarray(lam, float), (R,)).copy()
-    use_reg = bool(np.any(lam > 0.0))
+    # ridge rows are part of the residual layout: a shard of a larger problem must use the layout of the WHOLE problem (force_reg),
+    # or a rank whose rows all have lam == 0 would build Nd-wide residuals next to ranks building Nd + P
+    use_reg = bool(np.any(lam > 0.0)) if force_reg is None else bool(force_reg)
     Nr = Nd + (P if use_reg else 0)
     if sigma is None:
         sig = np.ones((R, Nr))
@@ -297,7 +299,8 @@ def fit_rows_sharded(model: str, num_psites: int, time_points, P0, init_cond, ta
     """``fit_rows_batch`` with the R problems block-partitioned over the ranks of an initialised ``torch.distributed`` group (one process
     per GPU): every rank fits its rows, then ONE all-gather of the per-row results [p | cost | J^T J] (P + 1 + P^2 doubles per row) gives
     every rank the complete ``RowsFit``.  Rows never interact, so the result equals the single-GPU fit row for row.  Without a process
-    group (or at world size 1) it is ``fit_rows_batch``."""
+    group (or at world size 1) it is ``fit_rows_batch``.  ``n_iter`` / ``n_solves`` / ``n_launches`` of the result are RANK-LOCAL counters
+    (the work this rank did), not totals."""
     import torch
     from ..distributed import shard_bounds, all_gather_replicas, _world, _control_device
     rank, world = _world()
@@ -306,6 +309,7 @@ def fit_rows_sharded(model: str, num_psites: int, time_points, P0, init_cond, ta
     if world == 1:
         return fit_rows_batch(model, num_psites, time_points, P0, init_cond, target, sigma=sigma, lam=lam, bounds=bounds, **kw)
     lo, hi = shard_bounds(R, rank, world)
+    kw = dict(kw, force_reg=bool(np.any(np.asarray(lam, float) > 0.0)))            # the residual layout of the whole problem on every rank
     rows = lambda a, nd: (np.asarray(a, float)[lo:hi] if np.asarray(a).ndim == nd else a)       # per-row arguments are sliced, shared ones passed on
     dev = _control_device()                                        # HBM for RCCL, host memory for the gloo tests
     if hi > lo:

@@ -4,11 +4,14 @@
   define_sensitivity_problem_ds/_rand  sensitivity/analysis.py:38-87
   _compute_Y                           sensitivity/analysis.py:90-176   (single-array host version; the batched path computes it
                                                                           on the GPU, fused into the solve kernel)
-  sensitivity_analysis_batch           the numerical core of _sensitivity_analysis (:197-331): sample -> N*(D+1) solves + Y in
+  _perturb_solve                       sensitivity/analysis.py:178-195  (the pool worker: one parameter set -> (i, sol, flat, Y))
+  _sensitivity_analysis                sensitivity/analysis.py:197-331  (reference argument list; returns (Si, best_trajectories))
+  sensitivity_analysis_batch           the numerical core of _sensitivity_analysis: sample -> N*(D+1) solves + Y in
                                        ONE launch -> analyze -> RMSE ranking against data -> best K curves (no plotting)
 """
 from __future__ import annotations
 
+import logging
 import math
 from typing import Dict, Optional, Sequence
 
@@ -16,6 +19,8 @@ import numpy as np
 
 from .. import config
 from . import morris
+
+logger = logging.getLogger(__name__)
 
 
 def compute_bound(value, perturbation=None):
@@ -127,3 +132,29 @@ def sensitivity_analysis_batch(popt: Sequence[float], time_points, num_psites: i
             out["rmse"] = rmse
             out["best_idx"] = np.argsort(rmse)[:K]
     return out
+
+
+def _perturb_solve(i_X_tuple):
+    """``(i, X, init_cond, num_psites, time_points) -> (i, solution [T, S], flat, Y)`` for one parameter set: the reference's pool worker.
+    ``_sensitivity_analysis`` does not call it per sample -- all samples are one launch."""
+    from ..models import model_module_for
+    i, X, init_cond, num_psites, time_points = i_X_tuple
+    solution, flat = model_module_for(config.ODE_MODEL).solve_ode(tuple(X), init_cond, num_psites, time_points)
+    return i, solution, flat, _compute_Y(solution, num_psites)
+
+
+def _sensitivity_analysis(pr_data, p_data, rna_data, popt, time_points, num_psites, psite_labels, state_labels, init_cond, gene,
+                          param_values: Optional[np.ndarray] = None, seed: Optional[int] = None):
+    """Morris screening around ``popt`` with the reference's argument list -> ``(Si, best_trajectories)``.
+
+    ``Si``: dict with ``names``, ``mu``, ``mu_star``, ``sigma``, ``mu_star_conf`` (the keys read from SALib's result; sigma-scaled
+    effects, 99 % bootstrap interval as sensitivity/analysis.py:264).  ``best_trajectories``: the K = ceil(10 N / levels) simulations
+    closest to the data, each ``{"params", "solution", "rmse"}``, ascending in RMSE (:286-297).  N = ``config.NUM_TRAJECTORIES``,
+    levels = ``config.PARAMETER_SPACE``; all N (D + 1) solves and their Y are ONE launch (the reference: a process pool of
+    ``os.cpu_count()`` workers).  ``psite_labels`` / ``state_labels`` only label the reference's plots and are unused; no plot is drawn.
+    ``param_values`` (keyword, not in the reference): a ready sample matrix, e.g. SALib's, instead of the built-in design."""
+    out = sensitivity_analysis_batch(popt, time_points, num_psites, init_cond, param_values=param_values, pr_data=pr_data, p_data=p_data,
+                                     rna_data=rna_data, seed=seed, normalize=config.NORMALIZE_MODEL_OUTPUT, **config.SOLVER_OPTS)
+    logger.info(f"[{gene}]      Sensitivity Analysis completed")
+    best = [{"params": out["param_values"][i], "solution": out["solutions"][i], "rmse": out["rmse"][i]} for i in out["best_idx"]]
+    return out["Si"], best

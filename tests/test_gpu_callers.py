@@ -1,0 +1,312 @@
+"""GPU: the reference-signature callers called with the reference's own argument lists, against fixtures made by
+running the reference's ``paramest.normest.normest`` / ``sensitivity.analysis._perturb_solve`` verbatim (tools/make_golden_normest.py) and
+its ``lossfn`` (tools/make_golden_loss.py).
+
+The fits are not bit-comparable (the reference iterates SciPy's TRF, the drop-in a batched bounded Levenberg-Marquardt); what is compared
+is what the callers consume: the score / error of the estimate (must not be worse than the reference's by more than the stated margin),
+the structure of the return values, and -- where the arithmetic is the same -- the numbers themselves."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import protein_models as pm
+from test_callers_cpu import PINS, write_tables
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture()
+def gene_setup(request, tmp_path, monkeypatch):
+    """Configure the package like the reference process that made the fixture: model, measurement tables, output directory."""
+    from phoskintime_amd import config, models
+    g = np.load(request.param)
+    p1, p2 = write_tables(tmp_path, g)
+    monkeypatch.setattr(config, "INPUT1_WSTD_PATH", str(p1)); monkeypatch.setattr(config, "INPUT2_PATH", str(p2))
+    monkeypatch.setattr(config, "OUT_DIR", str(tmp_path / "out"))
+    old = config.ODE_MODEL
+    models.set_model(str(g["model"]))
+    yield g, tmp_path
+    models.set_model(old)
+
+
+def _bounds(g):
+    return {str(k): tuple(v) for k, v in zip(g["bounds_keys"], g["bounds_vals"])}
+
+
+@pytest.mark.parametrize("gene_setup", PINS, ids=lambda f: f.stem, indirect=True)
+def test_normest_with_the_reference_argument_list(gene_setup):
+    from phoskintime_amd.paramest.normest import normest
+    from phoskintime_amd.paramest.toggle import estimate_parameters
+    g, tmp = gene_setup
+    model, n, t, gene = str(g["model"]), int(g["n"]), g["t"], str(g["gene"])
+    mid = pm.MODEL_IDS[model]
+    est, fits, errs, reg = normest(gene, g["pr_data"], g["p_data"], g["r_data"], g["y0"], n, t, _bounds(g), 0)
+    assert isinstance(est, list) and isinstance(fits, list) and isinstance(errs, list) and len(est) == len(fits) == len(errs) == 1
+    assert est[0].shape == g["est_params"][0].shape and fits[0][0].shape == g["fit_sol"].shape and fits[0][1].shape == g["fit_flat"].shape
+    assert np.all(est[0] >= 0.0) and np.all(est[0] <= 20.0 + 1e-9)
+    # the returned pieces are consistent with each other, computed independently by the oracle
+    sol_o, flat_o = pm.solve_ode(mid, est[0], g["y0"], n, t)
+    assert pm.band_error(fits[0][0], np.clip(pm.solve_tight(mid, est[0], g["y0"], n, t), 0, None)) <= 1.0
+    target = g["target"]
+    assert errs[0] == pytest.approx(np.sum(np.abs(flat_o - target) ** 2) / target.size, rel=1e-4)
+    # quality: the reference's own estimate, scored with the reference's score_fit, is the bar.  Both fits are regularised (different
+    # lambdas may win the scan), so the data error is compared with a margin and the composite score with a tighter one
+    score = pm.score_fit(est[0], target, flat_o)
+    score_ref = pm.score_fit(g["est_params"][0], target, g["fit_flat"])
+    assert score <= 1.10 * score_ref, (score, score_ref)
+    assert errs[0] <= 2.0 * float(g["error_vals"][0]) + 1e-4
+    lam = reg * est[0].size / np.sum(np.square(est[0]))                      # regularization_term = lambda / P * sum(theta^2)
+    assert np.min(np.abs(np.logspace(-2, 0, 10) - lam)) < 1e-9, lam            # a lambda of the reference's grid
+    # the confidence-interval table (normest.py:535-543)
+    import pandas as pd
+    ci = pd.read_csv(tmp / "out" / f"{gene}_confidence_intervals.csv")
+    assert list(ci.columns) == [str(c) for c in g["ci_file_columns"]] and list(ci["Parameter"]) == [str(c) for c in g["ci_file_params"]]
+    np.testing.assert_allclose(ci["Estimate"].values, est[0], rtol=1e-12)
+    # paramest/toggle.py: the tuple order the driver unpacks
+    mf, ep, seq, er, rt = estimate_parameters(gene, g["pr_data"], g["p_data"], g["r_data"], g["y0"], n, t, _bounds(g), 0)
+    np.testing.assert_array_equal(ep[0], est[0]); np.testing.assert_array_equal(seq, fits[0][1]); assert rt == reg and er == errs
+
+
+@pytest.mark.parametrize("gene_setup", PINS[:1], ids=lambda f: f.stem, indirect=True)
+def test_normest_bootstraps_and_unregularised(gene_setup):
+    from phoskintime_amd.paramest.normest import normest
+    g, _ = gene_setup
+    n, t, gene = int(g["n"]), g["t"], str(g["gene"])
+    est_b, fits_b, errs_b, reg_b = normest(gene, g["pr_data"], g["p_data"], g["r_data"], g["y0"], n, t, _bounds(g), 3)
+    assert est_b[0].shape == g["boot_est_params"][0].shape and np.isfinite(est_b[0]).all()
+    assert errs_b[0] <= 3.0 * float(g["boot_error_vals"][0]) + 1e-4            # mean of 3 refits of 5 %-noised targets: noisy by construction
+    est_u, _, errs_u, _ = normest(gene, g["pr_data"], g["p_data"], g["r_data"], g["y0"], n, t, _bounds(g), 0, use_regularization=False)
+    est_r, _, errs_r, _ = normest(gene, g["pr_data"], g["p_data"], g["r_data"], g["y0"], n, t, _bounds(g), 0, use_regularization=True)
+    assert errs_u[0] <= errs_r[0] * 1.05 + 1e-6                                 # without the ridge rows the data are fitted at least as well
+
+
+@pytest.mark.parametrize("gene_setup", PINS, ids=lambda f: f.stem, indirect=True)
+def test_lambda_scan_and_multistart_signatures(gene_setup):
+    from phoskintime_amd.paramest.normest import find_best_lambda, worker_find_lambda, _curve_fit_multistart
+    from phoskintime_amd.paramest.multistart import build_free_bounds
+    g, _ = gene_setup
+    model, n, t, gene = str(g["model"]), int(g["n"]), g["t"], str(g["gene"])
+    lb, ub = build_free_bounds(model, _bounds(g), n)
+    fb = (list(lb), list(ub))
+    # one lambda at a time (the reference's pool worker): scores against the reference's own scan of the same lambdas
+    for lam, want, key in zip(g["scan_lambdas"], g["scan_scores"], g["scan_keys"]):
+        l, sc, k = worker_find_lambda(float(lam), gene, g["target"], g["p0"], t, fb, g["y0"], n, g["p_data"], g["pr_data"])
+        assert l == float(lam) and k == str(key)
+        assert sc <= 1.05 * float(want), (lam, sc, want)                        # a local fit from the same p0: same basin or a better one
+    best, key = find_best_lambda(gene, g["target"], g["p0"], t, fb, g["y0"], n, g["p_data"], g["pr_data"], lambdas=g["scan_lambdas"])
+    assert best in [float(v) for v in g["scan_lambdas"]] and key == str(g["lambda_weight"])
+    # the multistart call exactly as normest makes it: a model_func closure without any attribute -> lambda recovered from one evaluation
+    from phoskintime_amd import models
+    lam_ref, P = float(g["lambda_reg"]), g["p0"].size
+
+    def model_func(tpts, *params):
+        pv = np.exp(np.asarray(params)) if model == "randmod" else np.asarray(params)
+        _, pf = models.solve_ode(pv, g["y0"], n, np.atleast_1d(tpts))
+        return np.concatenate([pf.flatten(), lam_ref / P * np.square(params)])
+    popt, pcov, best_score = _curve_fit_multistart(gene, model_func, t, g["ms_target_fit"], g["p0"], fb, g["ms_sigma"], g["y0"], n, g["target"],
+                                                   n_starts=48, jitter_frac=0.10, maxfev=20000, seed=42)
+    assert popt.shape == g["ms_popt"].shape and pcov is not None and pcov.shape == (P, P)
+    assert best_score <= 1.05 * float(g["ms_score"]), (best_score, float(g["ms_score"]))
+    with pytest.raises(ValueError):
+        _curve_fit_multistart(gene, model_func, t, g["ms_target_fit"], g["p0"], ([-np.inf] * P, list(ub)), g["ms_sigma"], g["y0"], n, g["target"])
+    with pytest.raises(ValueError):
+        _curve_fit_multistart(gene, model_func, t, g["ms_target_fit"][:-1], g["p0"], fb, g["ms_sigma"], g["y0"], n, g["target"])
+
+
+@pytest.mark.parametrize("gene_setup", PINS, ids=lambda f: f.stem, indirect=True)
+def test_perturb_solve_and_sensitivity_analysis(gene_setup, monkeypatch):
+    from phoskintime_amd import config
+    from phoskintime_amd.sensitivity import sensitivity_analysis
+    from phoskintime_amd.sensitivity.analysis import _perturb_solve, _sensitivity_analysis
+    g, _ = gene_setup
+    n, t = int(g["n"]), g["t"]
+    assert sensitivity_analysis is _sensitivity_analysis
+    i, sol, flat, Y = _perturb_solve((int(g["ps_i"]), tuple(g["ps_X"]), g["y0"], n, t))
+    assert i == int(g["ps_i"]) and str(g["ps_metric"]) == config.Y_METRIC
+    # the reference's own LSODA output at default tolerance is the comparison here: its error (up to 2.6 band widths at 32 states,
+    # DESIGN section 2) is far below that at 5 states
+    assert pm.band_error(sol, g["ps_sol"]) <= 1.0 and pm.band_error(flat, g["ps_flat"]) <= 1.0
+    assert Y == pytest.approx(float(g["ps_Y"]), rel=2e-6)
+    # the Morris driver with the reference's positional list; small design so that the CPU side of the test stays cheap
+    monkeypatch.setattr(config, "NUM_TRAJECTORIES", 12); monkeypatch.setattr(config, "PARAMETER_SPACE", 8)
+    popt = g["est_params"][0]
+    Si, best = _sensitivity_analysis(g["pr_data"], g["p_data"], g["r_data"], popt, t, n, ["a", "b"], ["R", "P"], g["y0"], str(g["gene"]), seed=5)
+    D = popt.size
+    assert set(("names", "mu", "mu_star", "sigma", "mu_star_conf")) <= set(Si) and len(Si["mu_star"]) == D
+    K = int(np.ceil(12 * 10 / 8))
+    assert len(best) == K and all(set(b) == {"params", "solution", "rmse"} for b in best)
+    rm = [b["rmse"] for b in best]
+    assert rm == sorted(rm) and best[0]["solution"].shape == (t.size, g["y0"].size) and best[0]["params"].shape == (D,)
+    # every stored trajectory is the solve of its stored parameters, and its RMSE is the reference's formula (analysis.py:268-284)
+    mid = pm.MODEL_IDS[str(g["model"])]
+    b0 = best[0]
+    assert pm.band_error(b0["solution"], np.clip(pm.solve_tight(mid, b0["params"], g["y0"], n, t), 0, None)) <= 1.0
+    s = b0["solution"]
+    rna = np.abs(s[-9:, 0] - g["r_data"].reshape(-1)) / 9
+    ps = np.abs(s[:, 2:2 + n] - g["p_data"].T) / g["p_data"].size
+    pr = np.abs(s[:, 1] - g["pr_data"].reshape(-1)) / 14
+    assert b0["rmse"] == pytest.approx(np.sqrt((np.mean(rna ** 2) + np.mean(ps ** 2) + np.mean(pr ** 2)) / 2.0), rel=1e-9)
+
+
+@pytest.mark.parametrize("m", [0, 2])
+def test_LOSS_FN_positional_matches_reference_sums(m, monkeypatch):
+    """global_model.lossfn.LOSS_FN(Y, ...18 positional arrays...) -> the sums the reference's own lossfn produced, all eight LOSS_MODEs,
+    single trajectory ([T, S] -> 3 floats) and batched ([B, T, S] -> 3 arrays)."""
+    from phoskintime_amd.global_model import lossfn, config as gcfg
+    from phoskintime_amd._capi import PhoskinError
+    gl = np.load(GOLD / f"network_loss_m{m}.npz")
+    g = np.load(GOLD / f"network_m{m}_small.npz")
+    # prot_map as cache.prepare_fast_loss_data builds it (cache.py): (block start, n_sites) -- (start, 2^n_sites) for the combinatorial topology
+    cnt = (1 << g["n_sites"].astype(np.int64)) if m == 2 else g["n_sites"]
+    prot_map = np.stack([g["offset_y"], cnt], axis=1).astype(np.int32)
+    args = [gl[k] for k in ("p_prot", "t_prot", "obs_prot", "w_prot", "p_rna", "t_rna", "obs_rna", "w_rna", "p_pho", "s_pho", "t_pho", "obs_pho", "w_pho")]
+    tail = [prot_map, int(gl["prot_base_idx"]), int(gl["rna_base_idx"]), int(gl["pho_base_idx"])]
+    monkeypatch.setattr(gcfg, "MODEL", m)
+    for mode in range(8):
+        monkeypatch.setattr(gcfg, "LOSS_MODE", mode)
+        lp, lr, lph = lossfn.LOSS_FN(gl["Y"], *args, *tail)
+        np.testing.assert_allclose(np.stack([lp, lr, lph], axis=1), gl["loss_sums"][mode], rtol=1e-12, atol=0, equal_nan=True)
+        one = lossfn.LOSS_FN(gl["Y"][1], *args, *tail)
+        assert isinstance(one, tuple) and len(one) == 3 and all(isinstance(v, float) for v in one)
+        np.testing.assert_allclose(one, gl["loss_sums"][mode][1], rtol=1e-12, atol=0, equal_nan=True)
+    assert (lossfn.loss_function_comb if m == 2 else lossfn.loss_function_noncomb)(gl["Y"][0], *args, *tail) == lossfn.LOSS_FN(gl["Y"][0], *args, *tail)
+    bad = list(args); bad[1] = gl["t_prot"].copy(); bad[1][0] = gl["Y"].shape[1]
+    with pytest.raises(PhoskinError):
+        lossfn.LOSS_FN(gl["Y"], *bad, *tail)
+    bad_map = prot_map.copy(); bad_map[-1, 0] = gl["Y"].shape[2]
+    with pytest.raises(PhoskinError):
+        lossfn.LOSS_FN(gl["Y"], *args, bad_map, *tail[1:])
+
+
+def test_run_sensitivity_analysis_with_system_object(tmp_path, monkeypatch):
+    """global_model.sensitivity.run_sensitivity_analysis(sys, idx, fitted_params, output_dir, metric) on a System-shaped object: the
+    DataFrame and the CSV the reference writes, equal to the batched core run with the same seed."""
+    import pandas as pd
+    from test_gpu_network import _fake_system
+    from phoskintime_amd.global_model import config as gcfg, sensitivity as gs, simulate as gsim
+    g = np.load(GOLD / "network_m0_small.npz")
+    monkeypatch.setattr(gcfg, "MODEL", 0); monkeypatch.setattr(gcfg, "SENSITIVITY_TRAJECTORIES", 6); monkeypatch.setattr(gcfg, "SENSITIVITY_LEVELS", 4)
+    monkeypatch.setattr(gcfg, "SENSITIVITY_TOP_CURVES", 5)
+    sysm, idx = _fake_system(g, 0)
+    fitted = {k: (float(sysm.tf_scale) if k == "tf_scale" else np.array(getattr(sysm, k), copy=True)) for k in gs._ORDER}
+    df = gs.run_sensitivity_analysis(sysm, idx, fitted, str(tmp_path), metric="total_signal")
+    assert list(df.columns) == ["Parameter", "mu_star", "sigma", "mu_star_conf"]
+    D = sum(np.size(v) for v in fitted.values())
+    assert len(df) == D and np.all(np.diff(df["mu_star"].values) <= 0)
+    on_disk = pd.read_csv(tmp_path / "sensitivity_indices.csv")
+    assert list(on_disk["Parameter"]) == list(df["Parameter"])
+    np.testing.assert_allclose(on_disk["mu_star"].values, df["mu_star"].values, rtol=1e-12)
+    tr = pd.read_csv(tmp_path / "sensitivity_trajectories.csv")
+    assert len(tr) == 5 and list(tr.columns[:2]) == ["id", "y_val"] and np.all(np.diff(tr["y_val"].values) <= 0)
+    core = gs.run_sensitivity_batch(gsim.engine_for(sysm), fitted, gcfg.TIME_POINTS_PROTEIN, gcfg.TIME_POINTS_RNA, gcfg.TIME_POINTS_PHOSPHO,
+                                    trajectories=6, num_levels=4, seed=gcfg.SEED, y0=sysm.y0())
+    by_name = dict(zip(core["problem"]["names"], core["Si"]["mu_star"]))
+    np.testing.assert_allclose(df["mu_star"].values, [by_name[p] for p in df["Parameter"]], rtol=1e-12)
+    # the pool worker's signature still works for one sample
+    shapes = {k: np.shape(v) if isinstance(v, np.ndarray) else () for k, v in fitted.items()}
+    i, y, dfp, dfr, dfph = gs._worker_simulation((3, core["param_values"][3], core["problem"]["names"], shapes, sysm, idx, gcfg.TIME_POINTS_PROTEIN,
+                                                  gcfg.TIME_POINTS_RNA, gcfg.TIME_POINTS_PHOSPHO, "total_signal"))
+    assert i == 3 and y == pytest.approx(core["Y"][3], rel=1e-6)
+
+
+def test_engine_outlives_the_system_it_was_built_from():
+    """eviction of the per-System cache must not close an engine a caller still holds."""
+    import gc
+    from test_gpu_network import _fake_system
+    from phoskintime_amd.global_model import simulate as gsim, config as gcfg
+    g = np.load(GOLD / "network_m0_small.npz")
+    gcfg.MODEL = 0
+
+    class Sys:                                     # weak-referenceable, unlike SimpleNamespace
+        pass
+    src, _ = _fake_system(g, 0)
+    s = Sys(); s.__dict__.update(src.__dict__)
+    eng = gsim.engine_for(s)
+    x = gsim.candidate_of(s, eng)
+    del s, src
+    gc.collect()
+    assert not gsim._engines                       # the cache entry went with the System
+    Y, st, _ = eng.simulate_batch(x[None], g["t_eval"])
+    assert not st.cpu().numpy().any() and np.isfinite(Y.cpu().numpy()).all()
+
+
+def test_contexts_are_per_thread_and_concurrent_host_calls_are_correct():
+    """``models.solve_ode`` from several threads at once.  Every thread gets its own pk_ctx; results equal the serial ones."""
+    import threading
+    from phoskintime_amd import batch
+    from phoskintime_amd.models import distmod
+    rng = np.random.default_rng(3)
+    n = 4
+    thetas = rng.uniform(0.2, 2.0, (64, 12)); y0 = np.ones(6); t = pm.TIME_POINTS
+    serial = [distmod.solve_ode(th, y0, n, t)[1] for th in thetas]
+    ctxs, out, errs = {}, {}, []
+
+    def work(k):
+        try:
+            ctxs[k] = batch.get_context()
+            for rep in range(3):
+                out[k] = [distmod.solve_ode(th, y0, n, t)[1] for th in thetas[k::4]]
+        except Exception as e:                      # pragma: no cover
+            errs.append(e)
+    th_ = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [x.start() for x in th_]; [x.join() for x in th_]
+    assert not errs
+    assert len({id(c) for c in ctxs.values()} | {id(batch.get_context())}) == 5
+    for k in range(4):
+        for a, b in zip(out[k], serial[k::4]):
+            np.testing.assert_array_equal(a, b)
+    # a context shared on purpose (the C side serialises the `_host` entry points): still correct
+    shared = batch.get_context()
+    import ctypes as C
+    from phoskintime_amd import _capi
+    res = {}
+
+    def raw(k):
+        th = np.ascontiguousarray(thetas[k:k + 1]); sol = np.empty((1, t.size, 6)); flat = np.empty((1, 79)); st = np.zeros(1, np.int32)
+        opts = _capi.default_opts()
+        for rep in range(20):
+            shared.check(shared.lib.pk_solve_protein_batch_host(shared.handle, 0, n, 1, th.ctypes.data, y0.ctypes.data, 0, t.ctypes.data, t.size, C.byref(opts),
+                                                                sol.ctypes.data, flat.ctypes.data, None, 0, st.ctypes.data, None))
+        res[k] = flat[0].copy()
+    th_ = [threading.Thread(target=raw, args=(k,)) for k in range(4)]
+    [x.start() for x in th_]; [x.join() for x in th_]
+    for k in range(4):
+        np.testing.assert_array_equal(res[k], serial[k])
+
+
+def test_process_gene_end_to_end(tmp_path, monkeypatch):
+    """paramest.core.process_gene on synthetic input frames: the reference's result dict (numerical entries), knock-outs in one launch."""
+    import pandas as pd
+    from phoskintime_amd import config, models
+    from phoskintime_amd.paramest.core import process_gene
+    g = np.load(GOLD / "pins_normest_distmod.npz")
+    p1, p2 = write_tables(tmp_path, g)
+    monkeypatch.setattr(config, "INPUT1_WSTD_PATH", str(p1)); monkeypatch.setattr(config, "INPUT2_PATH", str(p2))
+    monkeypatch.setattr(config, "NUM_TRAJECTORIES", 8); monkeypatch.setattr(config, "PARAMETER_SPACE", 4)
+    old = config.ODE_MODEL
+    models.set_model("distmod")
+    try:
+        gene, n, t = str(g["gene"]), int(g["n"]), g["t"]
+        xc = [f"x{i}" for i in range(1, 15)]
+        protein = pd.DataFrame([[gene, np.nan] + list(g["pr_data"][0])], columns=["GeneID", "Psite"] + xc)
+        kinase = pd.DataFrame([[gene, f"S_{10 * (i + 1)}"] + list(g["p_data"][i]) for i in range(n)], columns=["Gene", "Psite"] + xc)
+        mrna = pd.DataFrame([[gene] + list(g["r_data"][0])], columns=["mRNA"] + [f"x{i}" for i in range(1, 10)])
+        res = process_gene(gene, protein, kinase, mrna, t, {str(k): tuple(v) for k, v in zip(g["bounds_keys"], g["bounds_vals"])}, out_dir=str(tmp_path / "o"))
+    finally:
+        models.set_model(old)
+    for key in ("gene", "labels", "psite_labels", "estimated_params", "model_fits", "seq_model_fit", "observed_data", "errors", "final_params", "param_df",
+                "gene_psite_data", "mse", "mae", "pca_result", "ev", "tsne_result", "perturbation_analysis", "perturbation_curves_params", "knockout_results",
+                "regularization"):
+        assert key in res
+    assert res["seq_model_fit"].shape == (n, 14) and res["model_fits"].shape == (14, 2 + n) and len(res["knockout_results"]) == 4 * (n + 2)
+    assert res["labels"] == ["R", "P", "P1", "P2"] and list(res["param_df"].columns) == ["Time", "A", "B", "C", "D", "S1", "S2", "D1", "D2", "Regularization"]
+    wt = res["knockout_results"]["WT"]
+    np.testing.assert_allclose(wt["sol_ko"], res["model_fits"], rtol=1e-9, atol=1e-12)
+    ko = res["knockout_results"]["Transcription KO"]
+    assert ko["sol_ko"][-1, 0] < 1e-6 * max(1.0, wt["sol_ko"][-1, 0]) or ko["sol_ko"][-1, 0] < wt["sol_ko"][-1, 0]       # no transcription: mRNA decays
+    assert res["mse"] == pytest.approx(np.mean((np.concatenate([g["r_data"].ravel(), g["pr_data"].ravel(), g["p_data"].ravel()]) - res["model_fits_flat"]) ** 2)) \
+        if "model_fits_flat" in res else res["mse"] < 0.01
+    Si, curves = res["perturbation_analysis"], res["perturbation_curves_params"]
+    assert len(Si["mu_star"]) == 4 + 2 * n and len(curves) == int(np.ceil(8 * 10 / 4))

@@ -61,7 +61,28 @@ def test_sensitivities_match_central_differences_of_the_oracle(eng, model, n):
         ref_J = _oracle_jac(mid, th[b], y0, n, t)
         err = np.abs(dflat[b] - ref_J) / (1.0 + np.abs(ref_J))
         assert err.max() < SENS_RTOL, (model, n, b, err.max())
-        assert np.all(dflat[b][flat[b] == y0[0] if False else np.zeros_like(flat[b], bool)] == 0.0)
+        assert np.isfinite(dflat[b]).all()
+
+
+def test_clipped_entries_have_zero_derivative_rows(eng):
+    """flat is np.clip(sol, 0, None) flattened (distmod.py:112-134): where the clip is active the output is the constant 0, so its
+    parameter derivative is 0 -- the rule include/phoskin.h states for dflat.  Negative initial site states make the clip bite at the
+    early time points."""
+    n = 3
+    rng = np.random.default_rng(11)
+    th = rng.uniform(0.3, 1.5, size=(4, pm.n_params(0, n)))
+    y0 = np.array([1.0, 1.0, -0.5, 0.7, -0.2])
+    t = pm.TIME_POINTS
+    res = eng.solve_ode_sens_batch("distmod", th, y0, n, t)
+    raw = eng.solve_ode_sens_batch("distmod", th, y0, n, t, clip_nonneg=False)
+    flat, dflat = res.flat.cpu().numpy(), res.dflat.cpu().numpy()
+    fraw, draw = raw.flat.cpu().numpy(), raw.dflat.cpu().numpy()
+    clipped = fraw < 0.0
+    assert clipped.any() and (~clipped).any()
+    assert np.all(flat[clipped] == 0.0) and np.all(dflat[clipped] == 0.0)               # whole P-rows of zeros
+    np.testing.assert_array_equal(flat[~clipped], fraw[~clipped])
+    np.testing.assert_array_equal(dflat[~clipped], draw[~clipped])
+    assert np.abs(draw[clipped]).max() > 0.0                                            # the unclipped derivative there is not zero
 
 
 def test_sensitivities_follow_flat_postprocessing_and_batched_y0(eng):

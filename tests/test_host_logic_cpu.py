@@ -20,7 +20,8 @@ class _FakeEngine:
 
 def test_engine_cache_is_keyed_by_live_object_and_evicts(monkeypatch):
     """engines were cached under id(sys) with no reference to sys, so a recycled id handed a NEW System the OLD topology and
-    every System leaked its HBM.  Now: weak reference + identity check + finalizer that closes the engines."""
+    every System leaked its HBM.  Now: weak reference + identity check + finalizer that DROPS the cache entry.  ADVICE r2: the finalizer
+    must not close engines -- a caller may still hold one; an engine frees its HBM when its own last reference dies."""
     from phoskintime_amd.global_model import simulate as gsim
     monkeypatch.setattr(gsim.NetworkEngine, "from_system", classmethod(lambda cls, sys, model, device=None: _FakeEngine((sys.name, model))))
     gsim._engines.clear(); _FakeEngine.made = 0; _FakeEngine.closed.clear()
@@ -36,14 +37,14 @@ def test_engine_cache_is_keyed_by_live_object_and_evicts(monkeypatch):
     assert e2 is not e0 and e2.tag == ("a", 2)                             # one engine per kinetic model
     key = id(a)
     del a; gc.collect()
-    assert key not in gsim._engines and sorted(_FakeEngine.closed) == [("a", 0), ("a", 2)]      # evicted and closed with the System
+    assert key not in gsim._engines and _FakeEngine.closed == []           # evicted with the System; e0 / e2 are still held and stay usable
     # a stale entry under a recycled id is never handed out: simulate it by planting a dead weakref under a live object's id
     b = Sys("b")
     dead = Sys("dead"); import weakref; ref = weakref.ref(dead); del dead; gc.collect()
     stale = _FakeEngine(("stale", 0))
     gsim._engines[id(b)] = (ref, {0: stale})
     eb = gsim.engine_for(b, 0)
-    assert eb.tag == ("b", 0) and ("stale", 0) in _FakeEngine.closed
+    assert eb.tag == ("b", 0) and gsim._engines[id(b)][1] == {0: eb}
     # objects that cannot be weakly referenced: engines live on the object itself (SimpleNamespace), or a clear error (no __dict__)
     ns = types.SimpleNamespace(name="ns")
     e_ns = gsim.engine_for(ns, 0)

@@ -26,7 +26,8 @@ OUT = REPO / "tests" / "golden"
 TIME_POINTS = np.array([0.0, 0.5, 0.75, 1.0, 2.0, 4.0, 8.0, 16.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
 
 
-def import_reference():
+def import_reference(prepare=None):
+    """``prepare(tree)``: optional hook on the writable temp copy before anything is imported (config / data files of a test case)."""
     tmp = pathlib.Path(tempfile.mkdtemp(prefix="pk_ref_"))
     tree = tmp / "ref"
     shutil.copytree(REF, tree, ignore=shutil.ignore_patterns(".git", "docs", "static", "app", "background"))
@@ -40,6 +41,8 @@ def import_reference():
         "njit = jit = vectorize = _ident\n"
         "prange = range\n")
     (shim / "tomllib.py").write_text("from tomli import *\nfrom tomli import load, loads\n")
+    if prepare is not None:
+        prepare(tree)
     os.chdir(tree)
     os.environ.setdefault("MPLBACKEND", "Agg")
     sys.path.insert(0, str(shim))
