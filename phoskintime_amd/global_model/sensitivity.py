@@ -181,7 +181,8 @@ def run_sensitivity_analysis(sys, idx, fitted_params, output_dir, metric="total_
         v = fitted_params[k]
         params[k] = float(v) if k == "tf_scale" else np.asarray(v, dtype=float)
     res = run_sensitivity_batch(eng, params, config.TIME_POINTS_PROTEIN, config.TIME_POINTS_RNA, config.TIME_POINTS_PHOSPHO, metric=metric,
-                                seed=config.SEED if seed is None else seed, param_values=param_values, y0=np.asarray(sys.y0(), dtype=np.float64))
+                                perturbation=config.SENSITIVITY_PERTURBATION, trajectories=config.SENSITIVITY_TRAJECTORIES,
+                                num_levels=config.SENSITIVITY_LEVELS, seed=config.SEED if seed is None else seed, param_values=param_values, y0=np.asarray(sys.y0(), dtype=np.float64))
     Si = res["Si"]
     df_sens = pd.DataFrame({"Parameter": res["problem"]["names"], "mu_star": Si["mu_star"], "sigma": Si["sigma"], "mu_star_conf": Si["mu_star_conf"]})
     df_sens = df_sens.sort_values("mu_star", ascending=False)

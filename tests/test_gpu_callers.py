@@ -51,11 +51,17 @@ def test_normest_with_the_reference_argument_list(gene_setup):
     assert pm.band_error(fits[0][0], np.clip(pm.solve_tight(mid, est[0], g["y0"], n, t), 0, None)) <= 1.0
     target = g["target"]
     assert errs[0] == pytest.approx(np.sum(np.abs(flat_o - target) ** 2) / target.size, rel=1e-4)
-    # quality: the reference's own estimate, scored with the reference's score_fit, is the bar.  Both fits are regularised (different
-    # lambdas may win the scan), so the data error is compared with a margin and the composite score with a tighter one
+    # quality.  What curve_fit minimises is the sigma-weighted sum of squares (+ ridge rows); measured on the randmod fixture
+    # (tools/gpu_normest_dev.py) the reference's own popt has 5x the cost of the minimum -- its TRF differences an LSODA solution whose
+    # error (1.5e-8) is as large as the difference step, and stops on noise -- while all 48 lockstep starts here reach the same minimum.
+    # So the bar is: the weighted misfit of the data block is not above the reference's, and the composite score_fit (a DIFFERENT
+    # functional, by which the reference merely ranks its unconverged fits) stays within 25 % of the reference's pick
+    sig = g["ms_sigma"][:target.size]
+    wcost = lambda fl: 0.5 * float(np.sum(((fl - target) / sig) ** 2))
+    assert wcost(flat_o) <= 1.02 * wcost(g["fit_flat"]), (wcost(flat_o), wcost(g["fit_flat"]))
     score = pm.score_fit(est[0], target, flat_o)
     score_ref = pm.score_fit(g["est_params"][0], target, g["fit_flat"])
-    assert score <= 1.10 * score_ref, (score, score_ref)
+    assert score <= 1.25 * score_ref, (score, score_ref)
     assert errs[0] <= 2.0 * float(g["error_vals"][0]) + 1e-4
     lam = reg * est[0].size / np.sum(np.square(est[0]))                      # regularization_term = lambda / P * sum(theta^2)
     assert np.min(np.abs(np.logspace(-2, 0, 10) - lam)) < 1e-9, lam            # a lambda of the reference's grid
@@ -94,7 +100,7 @@ def test_lambda_scan_and_multistart_signatures(gene_setup):
     for lam, want, key in zip(g["scan_lambdas"], g["scan_scores"], g["scan_keys"]):
         l, sc, k = worker_find_lambda(float(lam), gene, g["target"], g["p0"], t, fb, g["y0"], n, g["p_data"], g["pr_data"])
         assert l == float(lam) and k == str(key)
-        assert sc <= 1.05 * float(want), (lam, sc, want)                        # a local fit from the same p0: same basin or a better one
+        assert sc <= 1.05 * float(want), (lam, sc, want)                        # a local fit from the same p0: the reference's basin or a better one
     best, key = find_best_lambda(gene, g["target"], g["p0"], t, fb, g["y0"], n, g["p_data"], g["pr_data"], lambdas=g["scan_lambdas"])
     assert best in [float(v) for v in g["scan_lambdas"]] and key == str(g["lambda_weight"])
     # the multistart call exactly as normest makes it: a model_func closure without any attribute -> lambda recovered from one evaluation
@@ -108,7 +114,14 @@ def test_lambda_scan_and_multistart_signatures(gene_setup):
     popt, pcov, best_score = _curve_fit_multistart(gene, model_func, t, g["ms_target_fit"], g["p0"], fb, g["ms_sigma"], g["y0"], n, g["target"],
                                                    n_starts=48, jitter_frac=0.10, maxfev=20000, seed=42)
     assert popt.shape == g["ms_popt"].shape and pcov is not None and pcov.shape == (P, P)
-    assert best_score <= 1.05 * float(g["ms_score"]), (best_score, float(g["ms_score"]))
+    # same lambda, same sigma, same 48 starts: the converged minimum of the weighted problem (cost) is at or below the reference's popt;
+    # score_fit of the pick within 25 % (see test_normest_with_the_reference_argument_list)
+    assert best_score <= 1.25 * float(g["ms_score"]), (best_score, float(g["ms_score"]))
+
+    def cost_of(p):
+        r = (model_func(t, *p) - g["ms_target_fit"]) / g["ms_sigma"]
+        return 0.5 * float(r @ r)
+    assert cost_of(popt) <= cost_of(g["ms_popt"]) * (1 + 1e-6)
     with pytest.raises(ValueError):
         _curve_fit_multistart(gene, model_func, t, g["ms_target_fit"], g["p0"], ([-np.inf] * P, list(ub)), g["ms_sigma"], g["y0"], n, g["target"])
     with pytest.raises(ValueError):
@@ -306,7 +319,10 @@ def test_process_gene_end_to_end(tmp_path, monkeypatch):
     np.testing.assert_allclose(wt["sol_ko"], res["model_fits"], rtol=1e-9, atol=1e-12)
     ko = res["knockout_results"]["Transcription KO"]
     assert ko["sol_ko"][-1, 0] < 1e-6 * max(1.0, wt["sol_ko"][-1, 0]) or ko["sol_ko"][-1, 0] < wt["sol_ko"][-1, 0]       # no transcription: mRNA decays
-    assert res["mse"] == pytest.approx(np.mean((np.concatenate([g["r_data"].ravel(), g["pr_data"].ravel(), g["p_data"].ravel()]) - res["model_fits_flat"]) ** 2)) \
-        if "model_fits_flat" in res else res["mse"] < 0.01
+    sol = res["model_fits"]                                                     # flat = [R(t5..), P(t0..), sites site-major] of the final solve
+    flat = np.concatenate([sol[5:, 0], sol[:, 1]] + [sol[:, 2 + i] for i in range(n)])
+    observed = np.concatenate([g["r_data"].ravel(), g["pr_data"].ravel(), g["p_data"].ravel()])
+    assert res["mse"] == pytest.approx(np.mean((observed - flat) ** 2), rel=1e-9) and res["mae"] == pytest.approx(np.mean(np.abs(observed - flat)), rel=1e-9)
+    np.testing.assert_allclose(res["seq_model_fit"], flat[23:].reshape(n, 14), rtol=1e-12)
     Si, curves = res["perturbation_analysis"], res["perturbation_curves_params"]
     assert len(Si["mu_star"]) == 4 + 2 * n and len(curves) == int(np.ceil(8 * 10 / 4))
