@@ -1,15 +1,22 @@
+#include <cstdlib>
 #include "pk_inst_sens.inc"
 hipError_t launch_sens_dist(const SensArgs&, hipStream_t);
 hipError_t launch_sens_succ(const SensArgs&, hipStream_t);
+hipError_t launch_sens_rows_dist(const SensArgs&, hipStream_t);
+hipError_t launch_sens_rows_succ(const SensArgs&, hipStream_t);
 
-// sizes with a sensitivity kernel: distmod / succmod n <= 14 (S <= 16 rows in one lane, 1 + P = 5 + 2 n <= 64 columns in one wave),
+// sizes with a sensitivity kernel: distmod / succmod n <= 14 (S <= 16 rows in one lane, 1 + P = 5 + 2 n <= 64 columns in one wave) and
+// n = 15 .. 62 (rows across the lanes of a group, eight columns per lane, the columns of a replica cut into chunks: pk_sens_rows.hpp),
 // randmod n <= 3 (2^n <= 8 coupled rows inverted in registers; 1 + P <= 16 columns) and n = 4, 5 (the inverse shared by the group in LDS)
 bool sens_available(int model, int n_sites) {
   if (model == M_RAND) return n_sites <= 5;
-  return n_sites <= 14;
+  return n_sites <= 62;
 }
 
 hipError_t launch_sens(const SensArgs& a, int model, hipStream_t st) {
+  // PK_SENS_ROWS=1 (read once): the rows-per-lane kernel at every size -- the A/B switch the tests use to hold the two kernels to agreement
+  static const int rows_env = [] { const char* v = getenv("PK_SENS_ROWS"); return v ? atoi(v) : 0; }();
+  if (model != M_RAND && (a.s.n_sites > 14 || rows_env == 1)) return model == M_DIST ? launch_sens_rows_dist(a, st) : launch_sens_rows_succ(a, st);
   if (model == M_DIST) return launch_sens_dist(a, st);
   if (model == M_SUCC) return launch_sens_succ(a, st);
   const int n = a.s.n_sites;

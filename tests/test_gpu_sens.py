@@ -1,6 +1,8 @@
 """GPU: forward parameter sensitivities (csrc/pk_sens.hpp, pk_solve_protein_sens_batch) against central differences of the oracle's
 integrator-free solution (oracle.protein_models.solve_exact_lti: matrix exponentials), and the Levenberg-Marquardt driver on them.
 Reference behaviour replaced: scipy.optimize.curve_fit's '2-point' differencing of models.solve_ode (paramest/normest.py:167-326)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -38,6 +40,8 @@ def _oracle_jac(model, th, y0, n, t):
 
 CASES = [("distmod", 1), ("distmod", 3), ("distmod", 4), ("distmod", 8), ("distmod", 13), ("distmod", 14),
          ("succmod", 1), ("succmod", 2), ("succmod", 5), ("succmod", 9), ("succmod", 14),
+         # rows-per-lane kernel (csrc/pk_sens_rows.hpp): 32-lane groups up to 30 sites (BASELINE config 3's size), 64-lane groups to 62
+         ("distmod", 15), ("distmod", 30), ("distmod", 31), ("distmod", 62), ("succmod", 15), ("succmod", 30), ("succmod", 47), ("succmod", 62),
          ("randmod", 1), ("randmod", 2), ("randmod", 3), ("randmod", 4), ("randmod", 5)]
 
 
@@ -109,12 +113,12 @@ def test_sensitivities_follow_flat_postprocessing_and_batched_y0(eng):
 
 def test_sizes_without_a_sensitivity_kernel_are_refused(eng):
     from phoskintime_amd._capi import PhoskinError
-    assert eng.sens_available("distmod", 14) and not eng.sens_available("distmod", 15)
+    assert eng.sens_available("distmod", 62) and not eng.sens_available("distmod", 63) and eng.sens_available("succmod", 62) and not eng.sens_available("succmod", 63)
     assert eng.sens_available("randmod", 5) and not eng.sens_available("randmod", 6)
     with pytest.raises(PhoskinError):
         eng.solve_ode_sens_batch("randmod", np.ones((1, pm.n_params(2, 6))), np.ones(pm.n_states(2, 6)), 6, pm.TIME_POINTS)
     with pytest.raises(PhoskinError):
-        eng.solve_ode_sens_batch("distmod", np.ones((1, pm.n_params(0, 20))), np.ones(22), 20, pm.TIME_POINTS)
+        eng.solve_ode_sens_batch("distmod", np.ones((1, pm.n_params(0, 63))), np.ones(65), 63, pm.TIME_POINTS)
     # failed replicas: flagged, NaN rows, the rest of the batch unaffected
     th = np.ones((3, 10)); th[1, 1] = np.nan
     r = eng.solve_ode_sens_batch("distmod", th, np.ones(5), 3, pm.TIME_POINTS)
@@ -241,3 +245,76 @@ def test_clipped_entries_have_zero_derivative(eng):
         ref_f = _oracle_flat(mid, th[b], y0, n, t)
         interior = (~clipped) & (ref_f > 1e-6)                      # away from the kink, where the difference quotient is a derivative
         assert np.max(np.abs(d[b][interior] - ref[interior]) / (1.0 + np.abs(ref[interior]))) < SENS_RTOL
+
+
+_AB_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from phoskintime_amd import batch
+from oracle import protein_models as pm
+out = {}
+for model, n in (("distmod", 4), ("distmod", 14), ("succmod", 3), ("succmod", 14)):
+    mid = pm.MODEL_IDS[model]
+    rng = np.random.default_rng(31 * mid + n)
+    th = rng.uniform(0.2, 2.0, size=(7, pm.n_params(mid, n))); y0 = rng.uniform(0.3, 1.5, size=(7, pm.n_states(mid, n)))
+    r = batch.solve_ode_sens_batch(model, th, y0, n, pm.TIME_POINTS, rtol=1e-10, atol=1e-12)
+    out[f"{model}_{n}_flat"] = r.flat.cpu().numpy(); out[f"{model}_{n}_dflat"] = r.dflat.cpu().numpy(); out[f"{model}_{n}_status"] = r.status.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_rows_kernel_agrees_with_the_column_kernel(tmp_path):
+    """The two sensitivity kernels are independent implementations (columns across lanes with O(S) in-lane solves vs rows across lanes
+    with cross-lane arrow / cyclic-reduction solves, chunked columns): at the sizes both cover (PK_SENS_ROWS=1 forces the rows kernel;
+    read once per process, hence child processes) they must agree far inside the tolerance both integrate to."""
+    import os, subprocess, sys
+    root = str(Path(__file__).resolve().parents[1])
+    res = {}
+    for tag, env in (("cols", "0"), ("rows", "1")):
+        f = tmp_path / f"{tag}.npz"
+        e = dict(os.environ, PK_SENS_ROWS=env)
+        subprocess.run([sys.executable, "-c", _AB_SCRIPT, root, str(f)], check=True, env=e, timeout=600)
+        res[tag] = np.load(f)
+    for key in res["cols"].files:
+        a, b = res["cols"][key], res["rows"][key]
+        if key.endswith("status"):
+            assert not a.any() and not b.any()
+        else:
+            assert np.max(np.abs(a - b) / (1.0 + np.abs(a))) < 2e-8, key
+
+
+def test_rows_kernel_postprocessing_chunks_and_failures(eng):
+    """n = 30 (P = 64: ten chunks of seven columns, the last one holding a single column): normalisation, clipping, batched y0, replica
+    independence and a failed replica, as test_sensitivities_follow_flat_postprocessing_and_batched_y0 checks them for the column kernel."""
+    rng = np.random.default_rng(5)
+    n, mid = 30, 0
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    B = 5
+    th = rng.uniform(0.2, 2.0, size=(B, P)); y0 = rng.uniform(0.5, 2.0, size=(B, S)); y0[:, 7] = -5.0
+    t = pm.TIME_POINTS
+    T = t.size
+    a = eng.solve_ode_sens_batch("distmod", th, y0, n, t)
+    b = eng.solve_ode_sens_batch("distmod", th, y0, n, t, normalize=True)
+    raw = eng.solve_ode_sens_batch("distmod", th, y0, n, t, clip_nonneg=False)
+    assert not a.status.cpu().numpy().any()
+    scale = np.concatenate([np.repeat(y0[:, :1], T - 5, axis=1), np.repeat(y0[:, 1:2], T, axis=1)] + [np.repeat(y0[:, 2 + j:3 + j], T, axis=1) for j in range(n)], axis=1)
+    fa, da = a.flat.cpu().numpy(), a.dflat.cpu().numpy()
+    np.testing.assert_allclose(b.flat.cpu().numpy() * scale, fa, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(b.dflat.cpu().numpy() * scale[:, :, None], da, rtol=1e-10, atol=1e-14)
+    fr, dr = raw.flat.cpu().numpy(), raw.dflat.cpu().numpy()
+    clipped = fr < 0.0
+    assert clipped.any() and np.all(fa[clipped] == 0.0) and np.all(da[clipped] == 0.0) and np.abs(dr[clipped]).max() > 0.0
+    np.testing.assert_array_equal(da[~clipped], dr[~clipped])
+    assert np.all(da[:, T - 5, :] == 0.0)                                       # P(t0) is data
+    plain = eng.solve_ode_batch("distmod", th, y0, n, t, want_sol=False).flat.cpu().numpy()
+    assert np.max(np.abs(fa - plain) / (1e-8 + 1e-6 * np.abs(plain))) < 0.1
+    one = eng.solve_ode_sens_batch("distmod", th[3:4], y0[3:4], n, t)
+    assert np.array_equal(one.dflat.cpu().numpy()[0], da[3]) and np.array_equal(one.flat.cpu().numpy()[0], fa[3])
+    th2 = th.copy(); th2[1, 40] = np.nan                                        # a parameter of chunk 5 only: every chunk of the replica must fail
+    r = eng.solve_ode_sens_batch("distmod", th2, y0, n, t)
+    st = r.status.cpu().numpy()
+    assert st[1] != 0 and not st[[0, 2, 3, 4]].any()
+    d2 = r.dflat.cpu().numpy()
+    at_t0 = [T - 5] + [T - 5 + T + j * T for j in range(n)]                      # rows written before the first step: values at t0 (data)
+    assert np.isnan(np.delete(d2[1], at_t0, axis=0)).all() and np.all(d2[1][at_t0] == 0.0)
+    assert np.array_equal(d2[0], da[0]) and np.array_equal(d2[4], da[4])

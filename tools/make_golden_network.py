@@ -236,8 +236,80 @@ def main_large(model_name):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def main_large_more(model_name, n_more=6):
+    """More reference-run truth at config 4 / 5 size (population parity must not be self-referential): the SAME N = 100
+    network as ``main_large`` (same generator stream, checked against the committed fixture), the second parameter set of that fixture
+    (which had no 1e-12 run) plus ``n_more`` new candidates -- half log-normal(0, 0.5) around the optimiser's defaults (the shape of
+    bench.py's config-5 population), half uniform over wide ranges -- each integrated by the reference's ``simulate_odeint`` VERBATIM at
+    rtol = atol = 1e-12.  Written after every candidate (tests/golden/netlarge_more_m<M>.npz), so an interrupted run keeps what it has.
+        python tools/make_golden_network.py large_more [model]"""
+    import pandas as pd, time
+    mods, tmp = import_reference(model_name)
+    cfg, net, bm, js, sim = mods["config"], mods["network"], mods["buildmat"], mods["jacspeedup"], mods["simulate"]
+    MODEL = cfg.MODEL
+    rng = np.random.default_rng(20260515 + 3 + 100 * MODEL)
+    N, n_ext, n_kp, n_tf = 100, 20, 20, 250
+    max_sites = 3 if MODEL == 2 else 6
+    prots, kinases, inter, tf_net = synth_frames(rng, N, max_sites, n_ext, n_kp, n_tf)
+    idx = net.Index(inter, tf_interactions=tf_net, kin_beta_map={k: float(rng.uniform(0.5, 1.5)) for k in kinases}, tf_beta_map={})
+    grid = np.asarray(cfg.TIME_POINTS_PROTEIN, float)
+    fc_rows = []
+    for k in idx.kinases:
+        base = 1.0 + 0.3 * np.sin(rng.uniform(0, 6) + np.arange(grid.size) * rng.uniform(0.2, 0.8))
+        for t, v in zip(grid, base):
+            fc_rows.append(dict(protein=k, time=float(t), fc=float(max(v, 1e-6))))
+    kin_in = net.KinaseInput(idx.kinases, pd.DataFrame(fc_rows))
+    W = bm.build_W_parallel(inter, idx, n_cores=1)
+    tf_mat = bm.build_tf_matrix(tf_net, idx, tf_beta_map={}, kin_beta_map={})
+    tf_deg = np.asarray(np.abs(tf_mat).sum(axis=1)).ravel().astype(np.float64)
+    tf_deg[tf_deg < 1e-12] = 1.0
+    nK = len(idx.kinases)
+    old = np.load(OUT / f"netlarge_m{MODEL}.npz")
+    defaults = dict(c_k=np.ones(nK), A_i=np.ones(idx.N), B_i=np.full(idx.N, 0.2), C_i=np.full(idx.N, 0.5), D_i=np.full(idx.N, 0.05),
+                    Dp_i=np.full(idx.total_sites, 0.05), E_i=np.ones(idx.N), tf_scale=0.1)
+    sysm = net.System(idx, W, tf_mat, kin_in, {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in defaults.items()}, tf_deg)
+    # the same network as the committed fixture, array for array
+    for key, val in (("W_indptr", sysm.W_indptr), ("W_indices", sysm.W_indices), ("W_data", sysm.W_data), ("TF_data", sysm.TF_data), ("kin_Kmat", sysm.kin_Kmat),
+                     ("offset_y", idx.offset_y), ("n_sites", idx.n_sites)):
+        np.testing.assert_array_equal(np.asarray(val), old[key], err_msg=key)
+    keys = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i")
+    psets = [{**{k: old[k][1].copy() for k in keys}, "tf_scale": float(old["tf_scale"][1])}]
+    r2 = np.random.default_rng(20260515 + 977 + 100 * MODEL)
+    for j in range(n_more):
+        if j % 2 == 0:
+            ps = {k: defaults[k] * np.exp(0.5 * r2.standard_normal(defaults[k].shape)) for k in keys}
+            ps["tf_scale"] = float(0.1 * np.exp(0.5 * r2.standard_normal()))
+        else:
+            ps = dict(c_k=r2.uniform(0.3, 2.0, nK), A_i=r2.uniform(0.3, 2.0, idx.N), B_i=r2.uniform(0.05, 1.0, idx.N), C_i=r2.uniform(0.1, 2.0, idx.N),
+                      D_i=r2.uniform(0.01, 0.5, idx.N), Dp_i=r2.uniform(0.01, 0.5, idx.total_sites), E_i=r2.uniform(0.2, 3.0, idx.N),
+                      tf_scale=float(r2.uniform(0.1, 4.0)))
+        psets.append(ps)
+    t_eval = old["t_eval"]
+    S = idx.state_dim
+    Yt = np.full((len(psets), t_eval.size, S), np.nan)
+    secs = np.zeros(len(psets))
+    for k, ps in enumerate(psets):
+        sysm.update(**ps)
+        if MODEL == 2:
+            js.build_S_cache_into(sysm.S_cache, sysm.W_indptr, sysm.W_indices, sysm.W_data, sysm.kin_Kmat, sysm.c_k)
+        t0 = time.time()
+        Yt[k] = sim.simulate_odeint(sysm, t_eval, 1e-12, 1e-12, 500000)
+        secs[k] = time.time() - t0
+        print(model_name, "large_more candidate", k, "LSODA 1e-12 done in", round(secs[k]), "s", flush=True)
+        d = dict(model=MODEL, done=k + 1, t_eval=t_eval, y0=sysm.y0(), Y_tight=Yt[:k + 1], seconds=secs[:k + 1], from_netlarge_index=np.array([1] + [-1] * k)[:k + 1],
+                 tf_scale=np.array([p["tf_scale"] for p in psets[:k + 1]]), **{kk: np.stack([p[kk] for p in psets[:k + 1]]) for kk in keys})
+        np.savez_compressed(OUT / f"netlarge_more_m{MODEL}.npz", **d)
+    print("wrote netlarge_more", model_name, flush=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "large_more":
+        if len(sys.argv) > 2:
+            main_large_more(sys.argv[2]); sys.exit(0)
+        procs = [subprocess.Popen([sys.executable, __file__, "large_more", m]) for m in MODEL_ID]
+        sys.exit(max(p.wait() for p in procs))
     if which == "large":
         if len(sys.argv) > 2:
             main_large(sys.argv[2]); sys.exit(0)
