@@ -226,8 +226,20 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
     if (model == PK_MODEL_RAND) {
       if (!resolvent_method(o.method) || o.stage_form)
         return fail(c, PK_ERR_UNSUPPORTED, "randmod n_sites >= 7: method must be LRP12 / LRP8 / RODAS4 in resolvent form (n = 7: LRP12 with the dense inverse; beyond: additive Runge-Kutta on the n-cube)");
-      if (pk::rand_dense_available(n_sites)) {                // n = 7: exact solves, the default method's step counts (pk_rand_dense.hpp)
+      // PK_WIDE_RAND_EXACT (read once) picks among the exact kernels and the approximate one -- the tests hold them to agreement:
+      //   1 (default)  parity elimination: the odd-popcount block of M is diagonal, the even Schur complement (64 x 64 at n = 7, 128 x 128
+      //                at n = 8) is inverted in registers (pk_rand_parity.hpp)
+      //   2            n = 7: the full 128 x 128 inverse in registers (pk_rand_dense.hpp, round 2's kernel); n = 8: block elimination over
+      //                the popcount levels with the Schur complements in LDS (pk_rand_level.hpp)
+      //   0            the n-cube kernel below (approximate factorisation), which stays the path for n >= 9
+      static const int exact_env = [] { const char* v = getenv("PK_WIDE_RAND_EXACT"); return v ? atoi(v) : 1; }();
+      if (n_sites == 7 && exact_env == 1 && pk::rand_dense_available(7)) { PK_HIP(c, pk::launch_rand_parity(a, c->stream)); return PK_OK; }
+      if (pk::rand_dense_available(n_sites) && exact_env != 0) {   // n = 7, PK_WIDE_RAND_EXACT=2 (PK_WIDE_RAND_DENSE=0 also selects the n-cube kernel)
         PK_HIP(c, pk::launch_rand_dense(a, c->stream));
+        return PK_OK;
+      }
+      if (n_sites == 8 && exact_env != 0) {
+        PK_HIP(c, exact_env == 2 ? pk::launch_rand_level(a, c->stream) : pk::launch_rand_parity(a, c->stream));
         return PK_OK;
       }
       double* scr = nullptr;
@@ -250,6 +262,14 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
       PK_HIP(c, pk::launch_wide_chain(a, model, c->stream));
     }
     PK_HIP(c, hipGetLastError());
+    return PK_OK;
+  }
+  // A/B switch of the tests: PK_RAND_LEVEL6=1 (read once) runs randmod n = 6 on the level-block kernel instead of the one-wave kernel
+  static const int level6_env = [] { const char* v = getenv("PK_RAND_LEVEL6"); return v ? atoi(v) : 0; }();
+  if (model == PK_MODEL_RAND && n_sites == 6 && level6_env == 1 && o.method == PK_METHOD_LRP12 && !o.stage_form) {
+    if (B > 0x7fffffffLL) return fail(c, PK_ERR_ARG, "batch too large for one launch");
+    PK_HIP(c, hipSetDevice(c->device));
+    PK_HIP(c, pk::launch_rand_level(a, c->stream));
     return PK_OK;
   }
   const bool rand_fast = model == PK_MODEL_RAND && resolvent_method(o.method) && (o.linsolve == PK_LINSOLVE_AUTO || a.S > 64) && !o.stage_form;

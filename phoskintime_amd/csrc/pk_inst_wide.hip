@@ -1,6 +1,8 @@
 // Instantiations + launchers of the workgroup-per-replica kernels (pk_wide.hpp) for systems beyond one wavefront's lane groups.
 #include "pk_wide.hpp"
 #include "pk_rand_dense.hpp"
+#include "pk_rand_level.hpp"
+#include "pk_rand_parity.hpp"
 #include "pk_launch.hpp"
 #include <atomic>
 #include <cstdlib>
@@ -28,6 +30,24 @@ hipError_t allow_lds(K fn, std::atomic<uint64_t>& ready) {
 
 // randmod n = 7 only: the 2^n x 2^n inverse must fit the register file of one workgroup (128 KB of a CU's 512 KB; n = 8 would need all of
 // it).  PK_WIDE_RAND_DENSE=0 (read once) sends n = 7 back to the approximate-factorisation kernel (tests exercise both).
+// randmod n = 8 (n = 6 on request): twisted block elimination over the popcount levels (pk_rand_level.hpp)
+hipError_t launch_rand_level(const SolveArgs& a_in, hipStream_t st) {
+  static const int dbg = [] { const char* v = getenv("PK_LEVEL_DEBUG"); return v ? atoi(v) : 0; }();     // dev timing switches (results are garbage when set)
+  SolveArgs a = a_in;
+  a.stage_form = dbg;
+  if (a.n_sites == 8) return launch_rand_level_one<8>(a, st);
+  if (a.n_sites == 6) return launch_rand_level_one<6>(a, st);
+  return hipErrorInvalidValue;
+}
+
+// randmod n = 8: odd-popcount states eliminated exactly, the 128 x 128 even Schur complement inverted in registers (pk_rand_parity.hpp)
+hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st) {
+  if (a.n_sites == 8) hipLaunchKernelGGL(rand_parity_kernel<8>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(8), st, a);
+  else if (a.n_sites == 7) hipLaunchKernelGGL(rand_parity_kernel<7>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(7), st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 bool rand_dense_available(int n_sites) {
   static const bool on = [] { const char* v = getenv("PK_WIDE_RAND_DENSE"); return !(v && v[0] == '0'); }();
   return on && n_sites == 7;
