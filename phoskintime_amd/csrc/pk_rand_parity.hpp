@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256) void rand_parity_kernel(const SolveArgs A) {
           v = -q2 * __builtin_fma(wgt(ma, bi_) * wgt(c1, bj_), dio[c1], wgt(ma, bj_) * wgt(c2, bi_) * dio[c2]);
         }
         a[ii][jj] = v;
+        // one entry at a time: left alone, the scheduler hoists the loads of all TS^2 entries (each with eight candidate terms) and the
+        // kernel needs 512 registers + scratch; the fill runs once per step, its latency does not matter
+        __builtin_amdgcn_sched_barrier(0);
       });
     });
 #pragma unroll 1

@@ -50,18 +50,22 @@ class GlobalODEBatch:
         return F
 
     def evaluate(self, X) -> np.ndarray:
-        """X [B, n_var] raw -> F [B, 3] (host).  Under an initialised ``torch.distributed`` group the population is block-partitioned over
-        the ranks (one process per GPU), every rank evaluates its shard, and ONE all-gather of the 24-byte objective rows (RCCL over xGMI)
-        gives every rank the whole F -- what pymoo's non-dominated sorting needs; candidates themselves never move."""
-        from ..distributed import shard_bounds, all_gather_replicas, _world
+        """X [B, n_var] raw -> F [B, 3] (host).  Under an initialised ``torch.distributed`` group the candidates are dealt round-robin over
+        the ranks (one process per GPU) in decreasing order of a stiffness proxy -- the largest physical rate of the candidate, which is what
+        sets its step count -- so that every rank integrates the same mix; every rank evaluates its rows, and ONE all-gather of the 24-byte
+        objective rows (RCCL over xGMI) gives every rank the whole F in population order -- what pymoo's non-dominated sorting needs;
+        candidates themselves never move."""
+        from ..distributed import interleaved_rows, all_gather_interleaved, cost_order, _world
         rank, world = _world()
         if world == 1:
             return self.evaluate_device(X).cpu().numpy()
         total = len(X)
-        lo, hi = shard_bounds(total, rank, world)
         dev = torch.device("cuda", self.eng.ctx.device)
-        Floc = self.evaluate_device(X[lo:hi]) if hi > lo else torch.empty((0, 3), dtype=torch.float64, device=dev)
-        return all_gather_replicas(Floc, total).cpu().numpy()
+        Xd = torch.as_tensor(np.asarray(X), device=dev) if not isinstance(X, torch.Tensor) else X.to(dev)
+        order = cost_order(Xd.max(dim=1).values)            # softplus is monotone: the largest raw entry is the largest rate
+        rows = interleaved_rows(total, rank, world, order)
+        Floc = self.evaluate_device(Xd[rows]) if rows.numel() else torch.empty((0, 3), dtype=torch.float64, device=dev)
+        return all_gather_interleaved(Floc, total, order).cpu().numpy()
 
     def close(self):
         if self.loss is not None:

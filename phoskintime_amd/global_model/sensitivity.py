@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from ..sensitivity import morris
-from ..distributed import shard_bounds, all_gather_with_status, shared_seed
+from ..distributed import interleaved_rows, all_gather_interleaved_with_status, shared_seed
 from . import config
 from .engine import NetworkEngine
 
@@ -118,20 +118,22 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
     times = np.unique(np.concatenate([times_p, times_r, times_ph]).astype(np.float64))
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
-    lo, hi = shard_bounds(total, rank, world)
+    # rows are dealt round-robin over the ranks: a Morris design walks through parameter space trajectory by trajectory, so contiguous
+    # blocks would hand each rank its own region (and its own step counts); interleaved, every rank integrates the same mix
+    rows = interleaved_rows(total, rank, world).to(Xd.device)
     lists, ld = eng.make_index_lists(times, times_p, times_r, times_ph)
     n_obs = ld["p_prot"].size + ld["p_rna"].size + ld["p_pho"].size
     pred = None
     try:
-        if hi > lo:
-            Y, status, _ = eng.simulate_batch(Xd[lo:hi], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
+        if rows.numel() > 0:
+            Y, status, _ = eng.simulate_batch(Xd if world == 1 else Xd[rows], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
             pred = eng.observables_batch(lists, Y, n_obs, eps=1e-12)
             yloc = scalar_metric_batch(pred, metric)
             yloc = torch.where(status != 0, torch.zeros_like(yloc), yloc)          # failed simulations contribute Y = 0
         else:
             dev = torch.device("cuda", eng.ctx.device)
             yloc = torch.empty(0, dtype=torch.float64, device=dev); status = torch.empty(0, dtype=torch.int32, device=dev)
-        Yall, stat = all_gather_with_status(yloc, status, total) if world > 1 else (yloc, status)      # the ONE collective
+        Yall, stat = all_gather_interleaved_with_status(yloc, status, total) if world > 1 else (yloc, status)      # the ONE collective
         Yall = torch.nan_to_num(Yall, nan=0.0, posinf=0.0, neginf=0.0)
         if design is not None:
             ee = morris.elementary_effects_device(design, Yall).cpu().numpy()      # EE [N, D] on the GPU: 8 N D bytes come back
@@ -146,7 +148,7 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
         Si = morris.analyze(problem, X, Yh, num_levels=num_levels, conf_level=conf_level, seed=seed)
     out = {"Si": Si, "problem": problem, "param_values": X, "Y": Yh, "status": stat.cpu().numpy()}
     if return_pred:
-        out.update(pred=pred, layout=ld, rows=(lo, hi), times=times)
+        out.update(pred=pred, layout=ld, rows=rows.cpu().numpy(), times=times)
     return out
 
 

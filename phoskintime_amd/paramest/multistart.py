@@ -296,37 +296,36 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
 
 
 def fit_rows_sharded(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None, **kw) -> RowsFit:
-    """``fit_rows_batch`` with the R problems block-partitioned over the ranks of an initialised ``torch.distributed`` group (one process
+    """``fit_rows_batch`` with the R problems dealt round-robin over the ranks of an initialised ``torch.distributed`` group (one process
     per GPU): every rank fits its rows, then ONE all-gather of the per-row results [p | cost | J^T J] (P + 1 + P^2 doubles per row) gives
     every rank the complete ``RowsFit``.  Rows never interact, so the result equals the single-GPU fit row for row.  Without a process
     group (or at world size 1) it is ``fit_rows_batch``.  ``n_iter`` / ``n_solves`` / ``n_launches`` of the result are RANK-LOCAL counters
     (the work this rank did), not totals."""
     import torch
-    from ..distributed import shard_bounds, all_gather_replicas, _world, _control_device
+    from ..distributed import interleaved_rows, all_gather_interleaved, _world, _control_device
     rank, world = _world()
     P0 = np.atleast_2d(np.asarray(P0, float))
     R, P = P0.shape
     if world == 1:
         return fit_rows_batch(model, num_psites, time_points, P0, init_cond, target, sigma=sigma, lam=lam, bounds=bounds, **kw)
-    lo, hi = shard_bounds(R, rank, world)
+    # rows dealt round-robin (rank r: rows r, r + W, ...): rows of one lambda / one weighting sit next to each other and converge alike
+    mine = interleaved_rows(R, rank, world).numpy()
     kw = dict(kw, force_reg=bool(np.any(np.asarray(lam, float) > 0.0)))            # the residual layout of the whole problem on every rank
-    rows = lambda a, nd: (np.asarray(a, float)[lo:hi] if np.asarray(a).ndim == nd else a)       # per-row arguments are sliced, shared ones passed on
+    rows = lambda a, nd: (np.asarray(a, float)[mine] if np.asarray(a).ndim == nd else a)       # per-row arguments are sliced, shared ones passed on
     dev = _control_device()                                        # HBM for RCCL, host memory for the gloo tests
-    if hi > lo:
-        fit = fit_rows_batch(model, num_psites, time_points, P0[lo:hi], rows(init_cond, 2), rows(target, 2), sigma=(None if sigma is None else rows(sigma, 2)),
+    if mine.size:
+        fit = fit_rows_batch(model, num_psites, time_points, P0[mine], rows(init_cond, 2), rows(target, 2), sigma=(None if sigma is None else rows(sigma, 2)),
                              lam=rows(lam, 1), bounds=tuple(rows(b, 2) for b in bounds), **kw)
-        Nr = fit.r.shape[1]
-        packed = np.concatenate([fit.p, fit.cost[:, None], fit.JTJ.reshape(hi - lo, P * P), fit.r], axis=1)
+        packed = np.concatenate([fit.p, fit.cost[:, None], fit.JTJ.reshape(mine.size, P * P), fit.r], axis=1)
         meta = (fit.n_iter, fit.n_solves, fit.n_launches)
     else:
-        Nr = 0
         packed = np.zeros((0, 0)); meta = (0, 0, 0)
     # every rank must offer the same row width: the residual length is known from the shapes alone
     Nd = np.asarray(target).shape[-1]
     Nr = Nd + (P if np.any(np.asarray(lam, float) > 0.0) else 0)
     if packed.shape[0] == 0:
         packed = np.zeros((0, P + 1 + P * P + Nr))
-    full = all_gather_replicas(torch.as_tensor(packed, device=dev), R).cpu().numpy()
+    full = all_gather_interleaved(torch.as_tensor(packed, device=dev), R).cpu().numpy()
     return RowsFit(p=full[:, :P], cost=full[:, P], JTJ=full[:, P + 1:P + 1 + P * P].reshape(R, P, P), r=full[:, P + 1 + P * P:], n_iter=meta[0], n_solves=meta[1],
                    n_launches=meta[2])
 

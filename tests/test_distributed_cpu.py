@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from phoskintime_amd.distributed import shard_bounds, all_gather_replicas, sharded_map, shared_seed, all_gather_with_status
+from phoskintime_amd.distributed import (shard_bounds, all_gather_replicas, sharded_map, shared_seed, all_gather_with_status, interleaved_rows, cost_order,
+                                         all_gather_interleaved, all_gather_interleaved_with_status, sharded_map_rows)
 
 
 def test_shard_bounds_cover_exactly_once():
@@ -68,8 +69,25 @@ def _worker(rank, world, port, total, q):
         fit = ms.fit_rows_sharded("distmod", 1, [0.0, 1.0], P0, np.ones(3), np.zeros(4), lam=np.zeros(R_), bounds=(np.zeros((R_, 3)), np.ones(3)))
         ok = ok and np.array_equal(fit.p, P0 * 2.0) and np.array_equal(fit.cost, P0.sum(axis=1)) and fit.JTJ.shape == (R_, 3, 3) \
             and np.array_equal(fit.JTJ[-1], np.outer(P0[-1], P0[-1])) and fit.r.shape == (R_, 4)
-        lo2, hi2 = shard_bounds(R_, rank, world)
-        ok = ok and ((hi2 == lo2 and not calls) or (calls and calls[0] == (hi2 - lo2, (hi2 - lo2, 3), (hi2 - lo2,))))      # per-row args sliced, shared passed on
+        mine = interleaved_rows(R_, rank, world).numel()
+        ok = ok and ((mine == 0 and not calls) or (calls and calls[0] == (mine, (mine, 3), (mine,))))      # per-row args sliced (interleaved rows), shared passed on
+        # interleaved partition: the gathered result equals the single-process one BIT FOR BIT, with and without a cost
+        # order; rows independent => fn(arange(total)) is the single-process answer
+        g = torch.Generator().manual_seed(5)
+        data = torch.rand((total, 3), dtype=torch.float64, generator=g)
+        kernel = lambda rows: torch.stack([data[rows, 0] * data[rows, 1], torch.sin(data[rows, 2]) + rows.to(torch.float64)], dim=1)
+        want = kernel(torch.arange(total))
+        ok = ok and torch.equal(sharded_map_rows(kernel, total), want)
+        cost = data[:, 2].clone()
+        ok = ok and torch.equal(sharded_map_rows(kernel, total, cost=cost), want)
+        rows_all = [interleaved_rows(total, r, world, cost_order(cost)) for r in range(world)]
+        ok = ok and sorted(torch.cat(rows_all).tolist()) == list(range(total)) and abs(rows_all[0].numel() - rows_all[-1].numel()) <= 1
+        if total >= 4:                # dealt in decreasing cost: the ranks' cost sums differ by less than the largest single cost
+            sums = [float(cost[r_].sum()) for r_ in rows_all]
+            ok = ok and abs(sums[0] - sums[1]) <= float(cost.max()) + 1e-12
+        mine_rows = interleaved_rows(total, rank, world)
+        v2, st2 = all_gather_interleaved_with_status(want[mine_rows], (mine_rows % 5).to(torch.int32), total)
+        ok = ok and torch.equal(v2, want) and st2.tolist() == [i % 5 for i in range(total)]
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -88,6 +106,23 @@ def test_sharded_map_gloo_world2(total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_interleaved_partition_single_process():
+    for total in (0, 1, 7, 8, 25728):
+        for world in (1, 2, 3, 8):
+            rows = [interleaved_rows(total, r, world) for r in range(world)]
+            assert sorted(torch.cat(rows).tolist()) == list(range(total))
+            assert max(x.numel() for x in rows) - min(x.numel() for x in rows) <= 1
+    c = torch.tensor([0.5, 3.0, 3.0, 0.1, 9.0])
+    assert cost_order(c).tolist() == [4, 1, 2, 0, 3]                      # decreasing, stable
+    x = torch.arange(5.0, dtype=torch.float64)
+    assert torch.equal(all_gather_interleaved(x, 5), x)
+    o = cost_order(c)
+    assert torch.equal(all_gather_interleaved(x[o], 5, o), x)             # single rank: local order = the cost order; back in global order
+    assert torch.equal(sharded_map_rows(lambda r: r.to(torch.float64) * 2, 6, cost=torch.rand(6)), torch.arange(6, dtype=torch.float64) * 2)
+    with pytest.raises(ValueError):
+        interleaved_rows(10, 2, 2)
 
 
 def test_single_rank_passthrough():

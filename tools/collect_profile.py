@@ -15,7 +15,7 @@ shutil.copy(stats[0], prefix + "_kernel_stats.csv")
 shutil.copy(os.path.join(out, "summary.txt"), prefix + "_summary.txt")
 if os.path.exists(os.path.join(out, "bench.json")) and os.path.getsize(os.path.join(out, "bench.json")):
     shutil.copy(os.path.join(out, "bench.json"), prefix + "_bench.json")
-d = {"round": 2, "kernel_match": kern, "workload": workload}
+d = {"round": int(os.environ.get("PK_ROUND", "3")), "kernel_match": kern, "workload": workload}
 for r in csv.DictReader(open(stats[0])):
     if kern in r["Name"]:
         d["kernel"] = r["Name"].replace("void ", "").split("(")[0]
