@@ -640,7 +640,7 @@ def test_network_beyond_the_register_kernel_limits_runs_through_the_lds_kernel()
     eng.close()
 
 
-LARGE = sorted((Path(__file__).resolve().parent / "golden").glob("netlarge_m*.npz"))
+LARGE = sorted((Path(__file__).resolve().parent / "golden").glob("netlarge_m[0-9].npz"))
 
 
 @pytest.mark.parametrize("f", LARGE, ids=lambda f: f.stem)

@@ -83,7 +83,7 @@ def test_oracle_frechet_restatement_matches_reference():
         assert abs(nm.frechet_distance(g[f"a{k}"], g[f"b{k}"]) - g["dist"][k]) <= 1e-12 * max(1.0, g["dist"][k])
 
 
-LARGE = sorted((Path(__file__).resolve().parent / "golden").glob("netlarge_m*.npz"))
+LARGE = sorted((Path(__file__).resolve().parent / "golden").glob("netlarge_m[0-9].npz"))
 
 
 def test_large_network_inventory():

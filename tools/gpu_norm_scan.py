@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 from pathlib import Path
 from phoskintime_amd.global_model import NetworkEngine
 band = lambda a, b: float(np.max(np.abs(a - b) / (1e-8 + 1e-6 * np.abs(b))))
-for f in sorted(Path("tests/golden").glob("netlarge_m*.npz")) + sorted(Path("tests/golden").glob("network_m*_medium.npz")) + sorted(Path("tests/golden").glob("network_m*_small.npz")):
+for f in sorted(Path("tests/golden").glob("netlarge_m[0-9].npz")) + sorted(Path("tests/golden").glob("network_m*_medium.npz")) + sorted(Path("tests/golden").glob("network_m*_small.npz")):
     g = np.load(f); eng = NetworkEngine.from_npz(g)
     X = np.stack([eng.pack_params(g["c_k"][k], g["A_i"][k], g["B_i"][k], g["C_i"][k], g["D_i"][k], g["Dp_i"][k], g["E_i"][k], g["tf_scale"][k]) for k in range(g["Y_tight"].shape[0])])
     out = [f.name]
