@@ -43,6 +43,61 @@ def algorithmic_flops_per_step(n: int) -> int:
     return (3 * n + 6) + S + (6 * n + 10) + 12 * (4 * n + 6) + 46 * S + 6 * S
 
 
+def algorithmic_flops_per_step_model(model: str, n: int) -> float:
+    """FP64 flops ONE LRP12 step of ONE replica needs, counted from the algorithm (never from a layout's instruction stream), per model:
+      distmod   arrow elimination: `algorithmic_flops_per_step`
+      succmod   Thomas on the (n + 2)-row chain: rhs 5n + 6, scaling S, factorisation 5n + 8, twelve solves 12 (5n + 6), accumulation 46 S, norm 6 S
+      randmod   2^n cube states (NM) + mRNA: rhs (2n + 2) NM; twelve solves + the inverse they use --
+                n <= 6: dense NM x NM inverse (Gauss-Jordan 2 NM^3) and 2 NM^2 per solve;
+                n = 7, 8: parity elimination (csrc/pk_rand_parity.hpp): NE = NM / 2 even states: fill NE (3n + 4 C(n,2)), inverse 2 NE^3,
+                per solve 2 NE^2 + 4 n NM for the two sparse sweeps;  accumulation 46 S, norm 6 S"""
+    if model == "distmod":
+        return float(algorithmic_flops_per_step(n))
+    S = n + 2
+    if model == "succmod":
+        return float((5 * n + 6) + S + (5 * n + 8) + 12 * (5 * n + 6) + 52 * S)
+    NM = 1 << n
+    S = NM + 1
+    base = (2 * n + 2) * NM + 52 * S
+    if n <= 6:
+        return float(base + 2 * NM ** 3 + 12 * 2 * NM ** 2)
+    NE = NM // 2
+    return float(base + NE * (3 * n + 4 * (n * (n - 1) // 2)) + 2 * NE ** 3 + 12 * (2 * NE ** 2 + 4 * n * NM))
+
+
+def network_algorithmic_flops_per_step(eng, stages: int = 6, solves: int = 5) -> float:
+    """FP64 flops ONE step of the additive order-4 integrator (ARK4(3)6L[2]SA: 6 stage right-hand sides, 5 block solves) needs for ONE
+    candidate of a linear-topology network: per stage the TF coupling 2 nnz(TF) + per protein (site sum n_s, double
+    squash ~20, block rhs 6 n_s + 10); per solve the arrow / Thomas elimination of every protein block 4 n_s + 8; the stage combinations of
+    the two tableaux (15 + 15 axpys of S), the two solution updates and the error norm: 90 S.  The kinase input (one CSR product per
+    BUCKET, not per stage) is left out."""
+    ns = np.asarray(eng._keep[2], dtype=np.float64)
+    nnz_tf = float(np.asarray(eng._keep[7]).size)
+    rhs = 2.0 * nnz_tf + float(np.sum(7.0 * ns + 30.0))
+    solve = float(np.sum(4.0 * ns + 8.0))
+    return stages * rhs + solves * solve + 90.0 * eng.S
+
+
+def roofline_fp64_entry(flops_per_launch: float, kernel_ms: float, note: str, pmc_glob: str = None, kernel_match: str = None) -> dict:
+    """{"achieved", "peak", "frac", ...}: algorithmic flops / measured kernel time; executed flops from a committed PMC profile of the same
+    kernel when one exists (labelled as such: counters are never re-measured inside bench.py)."""
+    ach = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+    out = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+           "algorithmic_flops_per_launch": flops_per_launch, "kernel_ms": kernel_ms, "how": note}
+    if pmc_glob:
+        prof = sorted((ROOT / "profiles").glob(pmc_glob))
+        if prof:
+            pj = json.loads(prof[-1].read_text())
+            if kernel_match is None or kernel_match in pj.get("kernel", ""):
+                t = pj.get("kernel_ns_largest_dispatch", pj.get("kernel_avg_ns_rocprof", 0.0)) * 1e-9
+                if t > 0 and "f64_flops_executed_per_launch" in pj:
+                    out.update({"executed_tflops_in_profile": pj["f64_flops_executed_per_launch"] / t / 1e12,
+                                "executed_frac_of_spec_peak_in_profile": pj["f64_flops_executed_per_launch"] / t / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                "valu_busy_frac_in_profile": pj.get("SQ_INSTS_VALU", 0.0) * 4.0 / (1024 * 2.1e9 * t),
+                                "profile": "profiles/%s (workload: %s)" % (prof[-1].name, pj.get("workload", "?"))})
+    return out
+
+
 def wait_for_library(lib_path: Path, local_rank: int):
     """A checkout without the (git-ignored) library: local rank 0 builds it (hipcc is part of the image) and renames it into place
     atomically; the others wait for the final name, with a bounded timeout and a clear error."""
@@ -346,6 +401,10 @@ def network_leg(dev):
            "integrator": "ARK4(3)6L[2]SA, linearly implicit on the per-protein block Jacobian (order 4, 5 block solves per step); max-norm error control",
            "algorithmic_bytes_per_candidate": 8 * (eng.n_var + eng.S + 3), "hbm_gbs_algorithmic": Bn * 8 * (eng.n_var + eng.S + 3) / (e0.elapsed_time(e1) * 1e-3) / 1e9,
            "finite_objectives": bool(torch.isfinite(F).all())}
+    fl_step = network_algorithmic_flops_per_step(eng)
+    out["roofline_fp64"] = roofline_fp64_entry(Bn * fl_step * (steps[0] + steps[1]), e0.elapsed_time(e1),
+                                               "network_algorithmic_flops_per_step (%.0f flop per step and candidate) x accepted + rejected steps x candidates / simulate_kernel_ms" % fl_step,
+                                               "r0*_network5*_pmc.json", "net_solve_ark")
     if g is not None:
         truth = g["Y_tight"][0]; y0c = Y[0].cpu().numpy()
         out["band_err_candidate0_vs_reference_lsoda_1e-12"] = float(np.max(np.abs(y0c - truth) / (1e-8 + 1e-6 * np.abs(truth))))
@@ -368,8 +427,9 @@ def network_leg(dev):
 
 
 def morris_leg(dev):
-    """BASELINE config 4: Morris screening of the network, 128 trajectories; like the reference (global_model/sensitivity.py:196-215) EVERY
-    entry of the fitted parameter set is varied (D = n_var; BASELINE's "200 params" is a smaller design of the same shape)."""
+    """BASELINE config 4: Morris screening of the network -- in its NAMED shape (128 trajectories x 200 varied parameters = 25 728 simulations:
+    the 200 entries are drawn once from the flat parameter vector, `vary=`) and in the reference's own shape (global_model/sensitivity.py:
+    196-215 varies EVERY entry: 128 x (n_var + 1) simulations, a superset workload)."""
     from phoskintime_amd.global_model import NetworkEngine, synthetic
     from phoskintime_amd.global_model import sensitivity as gs
     from phoskintime_amd.global_model import config as gcfg
@@ -385,15 +445,26 @@ def morris_leg(dev):
     tp, tr = gcfg.TIME_POINTS_PROTEIN, gcfg.TIME_POINTS_RNA
     gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, trajectories=2, num_levels=40, seed=1)
     torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    out = gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, trajectories=128, num_levels=40, seed=3)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t1
-    nsim = out["Y"].size
+    fl_step = network_algorithmic_flops_per_step(eng)
+    res = {}
+    vary200 = np.sort(np.random.default_rng(20260515 + 3).choice(eng.n_var, size=200, replace=False))
+    for label, vary in (("named_shape_128x200", vary200), ("every_entry_varied", None)):
+        t1 = time.perf_counter()
+        out = gs.run_sensitivity_batch(eng, fitted, tp, tr, tp, trajectories=128, num_levels=40, seed=3, vary=vary)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        nsim = out["Y"].size
+        D = len(out["problem"]["names"])
+        ms = out["mean_steps"] or [0.0, 0.0]
+        res[label] = {"workload": "Morris screening of the N=%d / S=%d network: 128 trajectories x (D = %d varied parameters + 1) = %d simulations at the settings of "
+                                  "simulate_and_measure -> fold-change observables -> total_signal -> elementary effects on the GPU" % (N, eng.S, D, nsim),
+                      "wall_s": dt, "simulations_per_s": nsim / dt, "flagged": int((out["status"] != 0).sum()), "finite_mu_star": bool(np.isfinite(out["Si"]["mu_star"]).all()),
+                      "mean_accepted_steps": ms[0], "mean_rejected_steps": ms[1],
+                      "roofline_fp64": roofline_fp64_entry(nsim * fl_step * (ms[0] + ms[1]), 1e3 * dt,
+                                                           "network_algorithmic_flops_per_step x steps x simulations / WALL time of the whole driver (design, simulate, observables, effects)")}
     eng.close()
-    return {"workload": "BASELINE config 4: Morris screening of the N=%d / S=%d network, 128 trajectories x (D = %d varied parameters + 1) = %d simulations at the "
-                        "settings of simulate_and_measure -> fold-change observables -> total_signal -> elementary effects on the GPU" % (N, eng.S, eng.n_var, nsim),
-            "wall_s": dt, "simulations_per_s": nsim / dt, "flagged": int((out["status"] != 0).sum()), "finite_mu_star": bool(np.isfinite(out["Si"]["mu_star"]).all())}
+    res["workload"] = "BASELINE config 4 (Morris sensitivity scan on the global_model network, 128 trajectories x 200 params), one GPU"
+    return res
 
 
 def lm_leg():
@@ -435,9 +506,13 @@ def secondary_legs(args, dev, tt, cpu):
     res = {}
     ctx = batch.get_context()
     try:
-        res["peaks_measured"] = {"hbm_copy_gbs": ctx.lib.pk_measure_hbm_gbs(ctx.handle, 2 << 30, 10), "fp64_fma_tflops": ctx.lib.pk_measure_fp64_fma_tflops(ctx.handle, 1 << 16),
-                                 "spec": {"hbm_gbs": HBM_PEAK_GBS, "fp64_valu_tflops": FP64_VALU_PEAK_TFLOPS},
-                                 "how": "pk_measure_hbm_gbs: 10 copies of 2 GiB (read + written bytes / time); pk_measure_fp64_fma_tflops: 16 independent v_fma_f64 chains per lane, 4 waves per SIMD"}
+        res["peaks_measured"] = {"hbm_copy_gbs": ctx.lib.pk_measure_hbm_gbs(ctx.handle, 2 << 30, 10),
+                                 "hbm_read_gbs": ctx.lib.pk_measure_hbm_stream_gbs(ctx.handle, 2 << 30, 10, 0), "hbm_write_gbs": ctx.lib.pk_measure_hbm_stream_gbs(ctx.handle, 2 << 30, 10, 1),
+                                 "fp64_fma_tflops": ctx.lib.pk_measure_fp64_fma_tflops(ctx.handle, 1 << 16),
+                                 "spec": {"hbm_gbs": HBM_PEAK_GBS, "hbm_gbs_achievable_per_guide": 6300.0, "fp64_valu_tflops": FP64_VALU_PEAK_TFLOPS},
+                                 "how": "pk_measure_hbm_gbs: 10 copies of 2 GiB, one 16 KiB tile per workgroup, 16 B per lane, non-temporal loads / stores (read + written bytes / time); "
+                                        "pk_measure_hbm_stream_gbs: the same tiles read-only / write-only; a copy sits below the read rate (bus turnarounds); "
+                                        "pk_measure_fp64_fma_tflops: 16 independent v_fma_f64 chains per lane, 4 waves per SIMD"}
     except Exception as e:
         res["peaks_measured"] = {"error": repr(e)}
     # BASELINE config 1 as the reference runs it: one distmod protein, ONE theta per call, through the drop-in models.solve_ode
@@ -485,9 +560,11 @@ def secondary_legs(args, dev, tt, cpu):
         res["lm_fit"] = {"error": repr(e)}
     try:
         other = {}
+        T_ = TGRID.size
         for label, mdl, nn, Bo in (("config1_size_distmod_n4_B65536", "distmod", 4, 65536), ("config2_succmod_n14_B4096", "succmod", 14, 4096),
                                    ("config2_size_succmod_n14_B65536", "succmod", 14, 65536), ("randmod_n4_B65536", "randmod", 4, 65536),
-                                   ("wide_distmod_n100_B4096", "distmod", 100, 4096), ("wide_succmod_n100_B4096", "succmod", 100, 4096), ("wide_randmod_n7_B1024", "randmod", 7, 1024), ("wide_randmod_n8_B1024", "randmod", 8, 1024)):
+                                   ("wide_distmod_n100_B4096", "distmod", 100, 4096), ("wide_succmod_n100_B4096", "succmod", 100, 4096), ("wide_randmod_n7_B1024", "randmod", 7, 1024), ("wide_randmod_n8_B1024", "randmod", 8, 1024),
+                                   ("wide_randmod_n9_B256_ncube_kernel", "randmod", 9, 256)):
             Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
             tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.0, 20.0, (Bo, Po)), device=dev)
             oo = batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False)
@@ -500,9 +577,16 @@ def secondary_legs(args, dev, tt, cpu):
                 batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
             torch.cuda.synchronize(dev)
             dto = (time.perf_counter() - t1) / reps
-            other[label] = {"replicas_per_s": Bo / dto, "ms": 1e3 * dto, "flagged": int((oo.status != 0).sum()), "mean_steps": float(oo.n_steps[:, 0].double().mean())}
+            nso = oo.n_steps.double().mean(dim=0).tolist()
+            other[label] = {"replicas_per_s": Bo / dto, "ms": 1e3 * dto, "flagged": int((oo.status != 0).sum()), "mean_steps": nso[0],
+                            "hbm_gbs_algorithmic": Bo * 8 * (Po + So + T_ * So) / dto / 1e9}
+            if not (mdl == "randmod" and nn >= 9):
+                fls = algorithmic_flops_per_step_model(mdl, nn)
+                prof = {"wide_randmod_n8_B1024": ("r03_*rand8_pmc.json", "rand_parity"), "wide_randmod_n7_B1024": ("r03_*rand7_pmc.json", "rand_parity")}.get(label, (None, None))
+                other[label]["roofline_fp64"] = roofline_fp64_entry(Bo * fls * (nso[0] + nso[1]), 1e3 * dto, "algorithmic_flops_per_step_model(%s, %d) = %.0f x steps x replicas / wall per launch" % (mdl, nn, fls), *prof)
         # forward sensitivities: flat and d flat / d theta of every replica from one launch (csrc/pk_sens.hpp)
-        for label, mdl, nn, Bo in (("sensitivities_distmod_n8_B65536", "distmod", 8, 65536), ("sensitivities_randmod_n4_B4096", "randmod", 4, 4096)):
+        for label, mdl, nn, Bo in (("sensitivities_distmod_n8_B65536", "distmod", 8, 65536), ("sensitivities_randmod_n4_B4096", "randmod", 4, 4096),
+                                   ("sensitivities_distmod_n30_B4096", "distmod", 30, 4096), ("sensitivities_succmod_n30_B4096", "succmod", 30, 4096)):
             Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
             tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.2, 2.0, (Bo, Po)), device=dev)
             batch.solve_ode_sens_batch(mdl, tho[:64], np.ones(So), nn, tt)
@@ -512,7 +596,11 @@ def secondary_legs(args, dev, tt, cpu):
                 rs = batch.solve_ode_sens_batch(mdl, tho, np.ones(So), nn, tt)
             torch.cuda.synchronize(dev)
             dto = (time.perf_counter() - t1) / 3
-            other[label] = {"jacobians_per_s": Bo / dto, "ms": 1e3 * dto, "columns": Po, "flagged": int((rs.status != 0).sum()), "mean_steps": float(rs.n_steps[:, 0].double().mean())}
+            nss = rs.n_steps.double().mean(dim=0).tolist()
+            fls = algorithmic_flops_per_step_model(mdl, nn) * (1 + Po)           # the same step for the state and for every tangent column
+            prof = ("r03_*sens_rows_pmc.json", "sens_rows") if label == "sensitivities_distmod_n30_B4096" else ("r02_g_sens_pmc.json", "sens_kernel") if label == "sensitivities_distmod_n8_B65536" else (None, None)
+            other[label] = {"jacobians_per_s": Bo / dto, "ms": 1e3 * dto, "columns": Po, "flagged": int((rs.status != 0).sum()), "mean_steps": nss[0],
+                            "roofline_fp64": roofline_fp64_entry(Bo * fls * (nss[0] + nss[1]), 1e3 * dto, "(1 + P) x algorithmic_flops_per_step_model x steps x replicas / wall per launch", *prof)}
         res["other_protein_configs"] = other
     except Exception as e:
         res["other_protein_configs"] = {"error": repr(e)}

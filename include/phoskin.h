@@ -311,6 +311,8 @@ double pk_time_solve_protein_batch(pk_ctx*, int iters, int model, int n_sites, i
  * sustained HBM copy rate in GB/s (read + written bytes; `bytes` >= 1 MiB per buffer, choose it well beyond the 256 MiB Infinity Cache)
  * and sustained FP64 vector FMA rate in TFLOP/s.  Both allocate and free their own buffers; < 0 on error. */
 double pk_measure_hbm_gbs(pk_ctx*, int64_t bytes, int iters);
+/* one-directional rates, bytes moved per second: mode 0 = read-only, 1 = write-only (a copy pays the bus turnarounds between the two) */
+double pk_measure_hbm_stream_gbs(pk_ctx*, int64_t bytes, int iters, int mode);
 double pk_measure_fp64_fma_tflops(pk_ctx*, int iters);
 
 #ifdef __cplusplus

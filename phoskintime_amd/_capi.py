@@ -65,7 +65,7 @@ SYMBOLS = (
     "pk_protein_n_states", "pk_protein_n_params", "pk_protein_flat_len",
     "pk_solve_protein_batch", "pk_solve_protein_sens_batch", "pk_protein_sens_available", "pk_rhs_protein_batch", "pk_jacobian_protein_batch", "pk_steady_state_protein_batch", "pk_morris_build_batch", "pk_morris_effects_batch", "pk_score_fit_batch",
     "pk_solve_protein_batch_host", "pk_solve_protein_sens_batch_host", "pk_rhs_protein_batch_host", "pk_jacobian_protein_batch_host",
-    "pk_time_solve_protein_batch", "pk_measure_hbm_gbs", "pk_measure_fp64_fma_tflops",
+    "pk_time_solve_protein_batch", "pk_measure_hbm_gbs", "pk_measure_hbm_stream_gbs", "pk_measure_fp64_fma_tflops",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
     "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_observables_batch", "pk_frechet_batch", "pk_loss_fn_batch_host", "pk_network_resolve_method",
@@ -140,6 +140,7 @@ def load():
     lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
     lib.pk_score_fit_batch.restype = i32; lib.pk_score_fit_batch.argtypes = [vp, i64, vp, i32, vp, vp, i32, vp, vp]
     lib.pk_measure_hbm_gbs.restype = dbl; lib.pk_measure_hbm_gbs.argtypes = [vp, i64, i32]
+    lib.pk_measure_hbm_stream_gbs.restype = dbl; lib.pk_measure_hbm_stream_gbs.argtypes = [vp, i64, i32, i32]
     lib.pk_measure_fp64_fma_tflops.restype = dbl; lib.pk_measure_fp64_fma_tflops.argtypes = [vp, i32]
     lib.pk_time_solve_protein_batch.restype = dbl
     lib.pk_time_solve_protein_batch.argtypes = [vp, i32] + solve_args[1:]

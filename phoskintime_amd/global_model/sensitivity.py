@@ -124,9 +124,11 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
     lists, ld = eng.make_index_lists(times, times_p, times_r, times_ph)
     n_obs = ld["p_prot"].size + ld["p_rna"].size + ld["p_pho"].size
     pred = None
+    mean_steps = None
     try:
         if rows.numel() > 0:
-            Y, status, _ = eng.simulate_batch(Xd if world == 1 else Xd[rows], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
+            Y, status, nst = eng.simulate_batch(Xd if world == 1 else Xd[rows], times, y0=y0, rtol=rtol, atol=atol, max_steps=5000 * times.size)
+            mean_steps = nst.double().mean(dim=0)
             pred = eng.observables_batch(lists, Y, n_obs, eps=1e-12)
             yloc = scalar_metric_batch(pred, metric)
             yloc = torch.where(status != 0, torch.zeros_like(yloc), yloc)          # failed simulations contribute Y = 0
@@ -146,7 +148,8 @@ def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, time
         Si = morris.analyze_effects(ee, problem.get("names"), conf_level=conf_level, seed=seed)
     else:
         Si = morris.analyze(problem, X, Yh, num_levels=num_levels, conf_level=conf_level, seed=seed)
-    out = {"Si": Si, "problem": problem, "param_values": X, "Y": Yh, "status": stat.cpu().numpy()}
+    out = {"Si": Si, "problem": problem, "param_values": X, "Y": Yh, "status": stat.cpu().numpy(),
+           "mean_steps": (None if mean_steps is None else [float(v) for v in mean_steps.cpu()])}      # accepted, rejected: this rank's rows
     if return_pred:
         out.update(pred=pred, layout=ld, rows=rows.cpu().numpy(), times=times)
     return out
