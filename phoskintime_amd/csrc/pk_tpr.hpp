@@ -14,9 +14,14 @@
 
 namespace pk {
 
-template <int NS> constexpr size_t tpr_lds_bytes() { return (size_t)(3 * (NS + 2) + 4) * 256 * sizeof(double); }
+// STAGE (the smallest systems only): a replica's output rows are S <= 6 doubles, 48 bytes at a 672-byte stride between the lanes of a
+// wave -- every store instruction touches 64 cache lines and leaves each of them partially written (measured: 1.39x the algorithmic
+// write traffic, profiles/r02_c_tpr_pmc.json).  With STAGE a lane collects its rows in a thread-private 128-byte line buffer in LDS
+// (slot-major, conflict-free) and writes a line only when it is complete (the block [T, S] of a replica is contiguous: its lines fill
+// up in order as the output times arrive), as eight 16-byte stores to ONE line.
+template <int NS, bool STAGE = false> constexpr size_t tpr_lds_bytes() { return (size_t)(3 * (NS + 2) + 4 + (STAGE ? 16 : 0)) * 256 * sizeof(double); }
 
-template <int MODEL, int NS, int METHOD>
+template <int MODEL, int NS, int METHOD, bool STAGE = false>
 __global__ __launch_bounds__(256) void tpr_kernel(const SolveArgs A) {
   static_assert(MODEL == M_DIST || MODEL == M_SUCC, "thread-per-replica kernels: distributive and successive models");
   using Tab = ResolventTab<METHOD>;
@@ -62,6 +67,25 @@ __global__ __launch_bounds__(256) void tpr_kernel(const SolveArgs A) {
   // ---- output / fused Morris metric (observables = every row: R, P, sites)
   static_for<NR + 4>([&](auto kc) { st(K_PV + decltype(kc)::value, 0.0); });
   const int T5 = T > 5 ? T - 5 : 0;
+  // line buffer of the staged path: 16 slots behind the parked values; element e of `sol` (global index) sits in slot e & 15
+  double* const lbuf = park + (size_t)(3 * NR + 4) * 256;
+  const long long e_first = rep * (long long)T * S, e_last = e_first + (long long)T * S - 1;
+  auto stage_store = [&](const long long e, const double r) {
+    const int slot = (int)(e & 15);
+    lbuf[slot * 256] = r;
+    if (slot == 15 || e == e_last) {                            // the line is complete (or the replica's block ends inside it): write it out
+      const long long line = e & ~15LL;
+      const int lo = (line < e_first) ? (int)(e_first - line) : 0;      // a block does not start on a line boundary: skip the neighbour's part
+      double* g = A.sol + line;
+      if (lo == 0 && slot == 15) {
+        using d2 = double __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { d2 w; w.x = lbuf[(2 * q) * 256]; w.y = lbuf[(2 * q + 1) * 256]; *(d2*)(g + 2 * q) = w; }
+      } else {
+        for (int q = lo; q <= slot; ++q) g[q] = lbuf[q * 256];
+      }
+    }
+  };
   auto emit = [&](const int k, const double (&v)[NR], const bool nan_fill) {
     double* solp = A.sol ? A.sol + (rep * T + k) * S : nullptr;
     double* fl = A.flat ? A.flat + rep * A.F : nullptr;
@@ -72,7 +96,7 @@ __global__ __launch_bounds__(256) void tpr_kernel(const SolveArgs A) {
       if (i < S) {
         r = nan_fill ? __builtin_nan("") : (A.clip ? ((v[i] < 0.0) ? 0.0 : v[i]) : v[i]);
         if (A.normalize && !nan_fill) r *= 1.0 / y0p[i];
-        if (solp) solp[i] = r;
+        if constexpr (STAGE) { if (solp) stage_store(e_first + (long long)k * S + i, r); }
         if (fl) {
           if (i == 0) { if (k >= 5) fl[k - 5] = r; }
           else if (i == 1) fl[T5 + k] = r;
@@ -81,6 +105,26 @@ __global__ __launch_bounds__(256) void tpr_kernel(const SolveArgs A) {
       }
       x[i] = r; loc += r;
     });
+    if constexpr (!STAGE) {
+      // the row as ALIGNED 16-byte stores (element pairs whose global index starts even; a single element at an odd start / end): three
+      // dwordx4 stores instead of six dwordx2 at S = 6 -- WRITE_SIZE counts 16-byte stores exactly, 8-byte ones as partial writes
+      if (solp) {
+        using d2 = double __attribute__((ext_vector_type(2)));
+        const int odd = (int)((e_first + (long long)k * S) & 1);
+        if (odd) solp[0] = x[0];
+        static_for<(NR + 1) / 2>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const int i0 = 2 * q + odd;                                // first element of the pair (run time: 2 q or 2 q + 1)
+          double a, b2;
+          if constexpr (2 * q + 1 < NR) a = odd ? x[2 * q + 1] : x[2 * q]; else a = x[2 * q];
+          if constexpr (2 * q + 2 < NR) b2 = odd ? x[2 * q + 2] : x[2 * q + 1];
+          else if constexpr (2 * q + 1 < NR) b2 = x[2 * q + 1];
+          else b2 = 0.0;
+          if (i0 + 1 < S) { d2 w; w.x = a; w.y = b2; *(d2*)(solp + i0) = w; }
+          else if (i0 < S) solp[i0] = a;
+        });
+      }
+    }
     if (A.metric) {
       st(K_M1, ld(K_M1) + loc);
       if (!(A.metric_id == PK_METRIC_TOTAL_SIGNAL || A.metric_id == PK_METRIC_MEAN_ACTIVITY)) {
