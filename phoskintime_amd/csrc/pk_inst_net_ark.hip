@@ -1,6 +1,7 @@
 // Instantiations + launcher of the order-4 network integrator (pk_network_solve_ark.hpp): topologies 0 / 1 / 4, site classes 4 / 6 / 8.
 #include "pk_network_solve_ark.hpp"
 #include <atomic>
+#include <cstdlib>
 
 namespace pk {
 
@@ -30,7 +31,7 @@ static hipError_t launch_one(const NetDev& n, const NetSolveArgs& a, long long B
   return hipSuccess;
 }
 
-template <int NB>
+template <int NB, bool EXACT>
 static hipError_t launch_comb(const NetDev& n, const NetSolveArgs& a, long long B, int threads, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     static std::atomic<uint64_t> ready{0};
@@ -39,17 +40,22 @@ static hipError_t launch_comb(const NetDev& n, const NetSolveArgs& a, long long 
     if (e != hipSuccess) return e;
     const uint64_t bit = dev < 64 ? (1ull << dev) : 0;
     if (!bit || !(ready.load(std::memory_order_acquire) & bit)) {
-      e = hipFuncSetAttribute((const void*)net_solve_ark2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      e = hipFuncSetAttribute((const void*)net_solve_ark2_kernel<NB, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
       ready.fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL((net_solve_ark2_kernel<NB>), dim3((unsigned)B), dim3(threads), lds, st, n, a);
+  hipLaunchKernelGGL((net_solve_ark2_kernel<NB, EXACT>), dim3((unsigned)B), dim3(threads), lds, st, n, a);
   return hipSuccess;
 }
 
 hipError_t launch_net_ark(const NetDev& n, const NetSolveArgs& a, int max_sites, long long B, int threads, size_t lds, hipStream_t st) {
-  if (n.model == 2) return max_sites <= 2 ? launch_comb<2>(n, a, B, threads, lds, st) : launch_comb<3>(n, a, B, threads, lds, st);
+  if (n.model == 2) {
+    // PK_ARK2_EXACT=0 (read once): round 2's approximate factorisation as the implicit operator (the A/B twin of the exact block solve)
+    static const bool exact = [] { const char* v = getenv("PK_ARK2_EXACT"); return !(v && v[0] == '0'); }();
+    if (max_sites <= 2) return exact ? launch_comb<2, true>(n, a, B, threads, lds, st) : launch_comb<2, false>(n, a, B, threads, lds, st);
+    return exact ? launch_comb<3, true>(n, a, B, threads, lds, st) : launch_comb<3, false>(n, a, B, threads, lds, st);
+  }
   const int cls = site_class(max_sites);
 #define PK_ARK(M)                                                                   \
   (cls == 4 ? launch_one<M, 4>(n, a, B, threads, lds, st) : cls == 6 ? launch_one<M, 6>(n, a, B, threads, lds, st) : launch_one<M, 8>(n, a, B, threads, lds, st))

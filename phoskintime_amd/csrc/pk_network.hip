@@ -232,8 +232,9 @@ int pk_network_resolve_method(const pk_net* n, const pk_solver_opts* opts) {
   const bool ark_fits = n->d.N <= 256 && n->max_sites <= (n->d.model == 2 ? 3 : 8) && linsolve != PK_LINSOLVE_STRUCTURED;
   const bool ark_ok = ark_fits && pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) <= 160 * 1024;
   if (method == PK_METHOD_ARK436) return ark_ok ? PK_METHOD_ARK436 : PK_ERR_UNSUPPORTED;
-  // combinatorial topology: the additive kernel exists (on request) but its step costs 2.8x a Rosenbrock-W step there: order 3 by default
-  return (ark_ok && n->d.model != 2 && method != PK_METHOD_ROS34PW2) ? PK_METHOD_ARK436 : PK_METHOD_ROS34PW2;
+  // [r3] the combinatorial topology takes the additive method by default too: with the EXACT block solve (parity elimination of the
+  // bit-pattern block, pk_network_solve_ark.hpp) it needs 4.6x fewer steps than the order-3 method and runs 1.8x faster at equal band error
+  return (ark_ok && method != PK_METHOD_ROS34PW2) ? PK_METHOD_ARK436 : PK_METHOD_ROS34PW2;
 }
 
 int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,

@@ -369,10 +369,19 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark_kernel(const NetDev n, c
 // An additive method accepts that as it stands: the implicit operator is simply A~ := g I - P (= A_block - F D_g^-1 K; it depends on the
 // step size, which the order conditions do not mind), stage solves are  P Y_i = g r_i  (the two sweeps),  A~ Y_i = g (Y_i - r_i) falls out
 // as before, and only stage 1 needs one product with P.  numpy model: tools/proto_ark_network.py solve_sgs.
-template <int NB>
+//
+// [r3] EXACT = true (the default since round 3): the implicit operator is the block Jacobian A itself, solved exactly.  The bit-pattern block
+// is bipartite like the per-protein random model (pk_rand_parity.hpp): every transition flips one bit, so the odd-popcount states couple
+// only to even ones and their diagonal block of W = g I - A is DIAGONAL.  Eliminating them leaves a Schur complement on the 2^(NB-1) even
+// states (4 x 4 at three sites, 2 x 2 at two): built from short sums, inverted by an unrolled Gauss-Jordan in registers (no pivoting:
+// M-matrix), 16 doubles.  A stage solve is then three in-thread passes (odd -> even right-hand side, 4 x 4 product, even -> odd), no more
+// expensive than the two sweeps -- and exact, so the additive method sees the stiffness it was promised: half the steps of the
+// approximate factorisation (numpy model tools/proto_ark_network.py: 540-580 against 1 100-1 400), and stage 1 needs A y, not P y.
+template <int NB, bool EXACT = true>
 __global__ __launch_bounds__(256, 2) void net_solve_ark2_kernel(const NetDev n, const NetSolveArgs A) {
   using namespace ark436;
   constexpr int NM = 1 << NB;
+  constexpr int NE = NM / 2;                         // even-popcount states
   constexpr int NR = 1 + NM;                         // rows of a block vector: mRNA, then the 2^NB bit-pattern states
   extern __shared__ __align__(16) double lds[];
   const int N = n.N, S = n.S;
@@ -461,15 +470,89 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark2_kernel(const NetDev n, 
     });
   };
   double winvR = 1.0, gB = 1.0, dinv[NM], dg[NM];
+  double sinv[EXACT ? NE : 1][EXACT ? NE : 1];       // EXACT: inverse of the even Schur complement
+  // magnitude of W[x][x ^ bit_j] (W = g I - A has it with a minus sign): inflow into x by phosphorylation of site j (x has the bit: rate
+  // S_j) or by dephosphorylation (x lacks it: rate E)
+  auto wgt = [&](auto xc, auto jc) { constexpr int x = decltype(xc)::value, j = decltype(jc)::value; if constexpr ((x >> j) & 1) return Sr[j]; else return Ei; };
   auto factor = [&](const double g) {
     gB = g + Bi;
     winvR = net_rcp(gB);
     static_for<NM>([&](auto mc) { constexpr int m = decltype(mc)::value; dg[m] = g + loss_of(mc); dinv[m] = net_rcp(dg[m]); });
+    if constexpr (EXACT) {
+      static_for<NE>([&](auto ac) {
+        constexpr int ea = decltype(ac)::value, a = 2 * ea + (__builtin_popcount(ea) & 1);
+        static_for<NE>([&](auto bc) {
+          constexpr int eb = decltype(bc)::value, b = 2 * eb + (__builtin_popcount(eb) & 1), d = a ^ b;
+          double v = 0.0;
+          if constexpr (d == 0) {
+            v = dg[a];
+            static_for<NB>([&](auto jc) {
+              constexpr int j = decltype(jc)::value, c = a ^ (1 << j);
+              v = __builtin_fma(-(wgt(std::integral_constant<int, a>{}, jc) * wgt(std::integral_constant<int, c>{}, jc)), dinv[c], v);
+            });
+          } else if constexpr (__builtin_popcount(d) == 2) {
+            constexpr int i1 = __builtin_ctz(d), i2 = __builtin_ctz(d & (d - 1)), c1 = a ^ (1 << i1), c2 = a ^ (1 << i2);
+            using I = std::integral_constant<int, i1>; using J = std::integral_constant<int, i2>;
+            v = -(wgt(std::integral_constant<int, a>{}, I{}) * wgt(std::integral_constant<int, c1>{}, J{}) * dinv[c1] +
+                  wgt(std::integral_constant<int, a>{}, J{}) * wgt(std::integral_constant<int, c2>{}, I{}) * dinv[c2]);
+          }
+          sinv[ea][eb] = v;
+        });
+      });
+      static_for<NE>([&](auto kc) {                    // in-place Gauss-Jordan inverse
+        constexpr int k = decltype(kc)::value;
+        const double rp = net_rcp(sinv[k][k]);
+        static_for<NE>([&](auto ic) {
+          constexpr int ii = decltype(ic)::value;
+          if constexpr (ii != k) {
+            const double ml = sinv[ii][k] * rp;
+            static_for<NE>([&](auto jc) { constexpr int jj = decltype(jc)::value; if constexpr (jj != k) sinv[ii][jj] = __builtin_fma(-ml, sinv[k][jj], sinv[ii][jj]); });
+            sinv[ii][k] = -ml;
+          }
+        });
+        static_for<NE>([&](auto jc) { constexpr int jj = decltype(jc)::value; if constexpr (jj != k) sinv[k][jj] *= rp; });
+        sinv[k][k] = rp;
+      });
+    }
   };
-  // x = P^-1 r : forward sweep (ascending masks), rescale, backward sweep (descending masks)
+  // A Y of the block (EXACT: stage 1)
+  auto block_matvec = [&](const double (&Yv)[NR], double (&out)[NR]) {
+    out[0] = -Bi * Yv[0];
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double a = (m == 0) ? Ci * Yv[0] : 0.0;
+      static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value; a = __builtin_fma(wgt(mc, jc), Yv[1 + (m ^ (1 << j))], a); });
+      out[1 + m] = a - loss_of(mc) * Yv[1 + m];
+    });
+  };
+  // EXACT: x = (g I - A)^-1 r by parity elimination;  else x = P^-1 r : forward sweep (ascending masks), rescale, backward sweep (descending masks)
   auto block_solve = [&](const double (&r)[NR], double (&x)[NR]) {
     const double xR = r[0] * winvR;
     x[0] = xR;
+    if constexpr (EXACT) {
+      double re[NE], xe[NE];
+      const double r0 = r[1] + Ci * xR;                // the R -> state 0 coupling moved to the right-hand side
+      auto rr = [&](auto mc) { constexpr int m = decltype(mc)::value; if constexpr (m == 0) return r0; else return r[1 + m]; };
+      static_for<NE>([&](auto ac) {                    // r'_e = r_e - W_eo D_o^-1 r_o
+        constexpr int ea = decltype(ac)::value, a = 2 * ea + (__builtin_popcount(ea) & 1);
+        double v = rr(std::integral_constant<int, a>{});
+        static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value, c = a ^ (1 << j); v = __builtin_fma(wgt(std::integral_constant<int, a>{}, jc) * dinv[c], rr(std::integral_constant<int, c>{}), v); });
+        re[ea] = v;
+      });
+      static_for<NE>([&](auto ac) {
+        constexpr int ea = decltype(ac)::value, a = 2 * ea + (__builtin_popcount(ea) & 1);
+        double v = sinv[ea][0] * re[0];
+        static_for<NE - 1>([&](auto bc) { constexpr int eb = 1 + decltype(bc)::value; v = __builtin_fma(sinv[ea][eb], re[eb], v); });
+        xe[ea] = v; x[1 + a] = v;
+      });
+      static_for<NE>([&](auto oc) {                    // x_o = D_o^-1 (r_o - W_oe x_e)
+        constexpr int eo = decltype(oc)::value, c = 2 * eo + 1 - (__builtin_popcount(eo) & 1);
+        double v = rr(std::integral_constant<int, c>{});
+        static_for<NB>([&](auto jc) { constexpr int j = decltype(jc)::value, a = c ^ (1 << j), ea = a >> 1; v = __builtin_fma(wgt(std::integral_constant<int, c>{}, jc), xe[ea], v); });
+        x[1 + c] = v * dinv[c];
+      });
+      return;
+    }
     static_for<NM>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       double a = r[1 + m] + ((m == 0) ? Ci * xR : 0.0);
@@ -535,12 +618,12 @@ __global__ __launch_bounds__(256, 2) void net_solve_ark2_kernel(const NetDev n, 
       const double g = net_rcp(hs * GAM);
       factor(g);
       double Y[NR], w[NR], v[NR], sb[NR], se[NR];
-      // ---- stage 1: Y_1 = y_n ;  h A~ y = h (g y - P y)
+      // ---- stage 1: Y_1 = y_n ;  EXACT: h A y ;  else h A~ y = h (g y - P y)
       rhs_block(y, w);
-      apply_P(y, v);
+      if constexpr (EXACT) block_matvec(y, v); else apply_P(y, v);
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
-        w[k] *= hs; v[k] = hs * (g * y[k] - v[k]);
+        w[k] *= hs; v[k] = EXACT ? hs * v[k] : hs * (g * y[k] - v[k]);
         sb[k] = B[0] * w[k]; se[k] = EB[0] * w[k];
       }
       static_for<4>([&](auto ic) {
