@@ -131,7 +131,11 @@ int pk_protein_n_states(int model, int n_sites);           /* S, or PK_ERR_* */
 int pk_protein_n_params(int model, int n_sites);           /* P */
 int pk_protein_flat_len(int model, int n_sites, int T);    /* (T-5) + T + n_sites*T  (distmod.py:125-134) */
 
-/* Replaces, for a whole batch of parameter vectors, models.solve_ode(params, init_cond, num_psites, t)
+/* (state conventions, [r3]: randmod n_sites = 7, 8 integrate with the default LRP12 on EXACT solves -- the odd-popcount block of I - q J is
+ *  diagonal, its even Schur complement is inverted in the registers of one workgroup, csrc/pk_rand_parity.hpp; n_sites >= 9: the additive
+ *  method on the n-cube, csrc/pk_wide.hpp.)
+ *
+ * Replaces, for a whole batch of parameter vectors, models.solve_ode(params, init_cond, num_psites, t)
  *   -> (sol, flat)   [models/__init__.py:12; distmod.py:93-134, succmod.py:114-152, randmod.py:249-305]
  * and, fused behind it, sensitivity.analysis._compute_Y (sensitivity/analysis.py:90-176).
  *   theta [B,P]; y0 [S] (shared) or [B,S]; t [T] with t[0] the initial time, strictly increasing;
@@ -149,8 +153,12 @@ int pk_solve_protein_batch(pk_ctx*, int model, int n_sites, int64_t B,
  *   flat [B,F]; dflat [B,F,P] (row-major: the P derivatives of one flat entry are contiguous); status / n_steps as above.
  * The derivative follows flat's own post-processing: 0 where the value was clipped at 0, scaled by 1 / y0 under opts->normalize.
  * Tangents are held to the same rtol / atol as the states (maximum norm over all columns).  Method LRP12 only.
- * Sizes: pk_protein_sens_available(model, n_sites) != 0 -- distmod / succmod n_sites <= 14, randmod n_sites <= 5; PK_ERR_UNSUPPORTED beyond
- * (callers difference pk_solve_protein_batch there, as phoskintime_amd.paramest.fit_rows_batch does). */
+ * Sizes: pk_protein_sens_available(model, n_sites) != 0 -- distmod / succmod n_sites <= 62 (up to 14: one column per lane, csrc/pk_sens.hpp;
+ * beyond: rows across the lanes, eight columns per lane, chunked columns, csrc/pk_sens_rows.hpp), randmod n_sites <= 7 (6 and 7: the
+ * parity-eliminated inverse in registers serving eight columns per workgroup, csrc/pk_rand_sens.hpp); PK_ERR_UNSUPPORTED beyond (callers
+ * difference pk_solve_protein_batch there, as phoskintime_amd.paramest.fit_rows_batch does).  Kernels that cut the columns of a replica
+ * into chunks integrate the state once per chunk with its own step-size control: every column is within rtol / atol of the exact
+ * derivative, the chunks are not bit-coupled; `status` is the OR over the chunks. */
 int pk_protein_sens_available(int model, int n_sites);
 int pk_solve_protein_sens_batch(pk_ctx*, int model, int n_sites, int64_t B,
                                 const double* theta, const double* y0, int y0_is_batched,

@@ -162,7 +162,7 @@ def solve_ode_batch(model, theta: ArrayLike, init_cond: ArrayLike, num_psites: i
 
 
 def sens_available(model, num_psites: int) -> bool:
-    """True where ``solve_ode_sens_batch`` has a kernel (distmod / succmod n <= 14, randmod n <= 5).  Pure host arithmetic."""
+    """True where ``solve_ode_sens_batch`` has a kernel (distmod / succmod n <= 62, randmod n <= 7).  Pure host arithmetic."""
     return bool(_capi.load().pk_protein_sens_available(model_id(model), int(num_psites)))
 
 

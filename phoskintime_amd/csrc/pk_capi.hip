@@ -424,7 +424,7 @@ int pk_solve_protein_sens_batch(pk_ctx* c, int model, int n_sites, int64_t B, co
   if (B < 0) return fail(c, PK_ERR_ARG, "B must be >= 0");
   if (T < 1) return fail(c, PK_ERR_ARG, "T must be >= 1");
   if (!pk::sens_available(model, n_sites))
-    return fail(c, PK_ERR_UNSUPPORTED, "forward sensitivities: distmod / succmod n_sites <= 62, randmod n_sites <= 5 (difference the batched solve beyond)");
+    return fail(c, PK_ERR_UNSUPPORTED, "forward sensitivities: distmod / succmod n_sites <= 62, randmod n_sites <= 7 (difference the batched solve beyond)");
   if (B == 0) return PK_OK;
   if (!theta || !y0 || !t || !flat || !dflat) return fail(c, PK_ERR_ARG, "theta, y0, t, flat and dflat must be non-null");
   pk_solver_opts o;
@@ -478,7 +478,7 @@ int pk_solve_protein_sens_batch_host(pk_ctx* c, int model, int n_sites, int64_t 
   if (rc) return rc;
   if (B < 0 || T < 1) return fail(c, PK_ERR_ARG, "B must be >= 0 and T >= 1");
   if (!pk::sens_available(model, n_sites))
-    return fail(c, PK_ERR_UNSUPPORTED, "forward sensitivities: distmod / succmod n_sites <= 62, randmod n_sites <= 5 (difference the batched solve beyond)");
+    return fail(c, PK_ERR_UNSUPPORTED, "forward sensitivities: distmod / succmod n_sites <= 62, randmod n_sites <= 7 (difference the batched solve beyond)");
   if (B == 0) return PK_OK;
   if (!theta || !y0 || !t || !flat || !dflat) return fail(c, PK_ERR_ARG, "theta, y0, t, flat and dflat must be non-null");
   const size_t S = pk::n_states(model, n_sites), P = pk::n_params(model, n_sites), F = pk_protein_flat_len(model, n_sites, T);

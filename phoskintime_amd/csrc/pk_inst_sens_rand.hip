@@ -4,12 +4,14 @@ hipError_t launch_sens_dist(const SensArgs&, hipStream_t);
 hipError_t launch_sens_succ(const SensArgs&, hipStream_t);
 hipError_t launch_sens_rows_dist(const SensArgs&, hipStream_t);
 hipError_t launch_sens_rows_succ(const SensArgs&, hipStream_t);
+hipError_t launch_rand_sens(const SensArgs&, hipStream_t);          // randmod n = 6, 7 (pk_rand_sens.hpp, instantiated with the workgroup-per-replica kernels)
 
 // sizes with a sensitivity kernel: distmod / succmod n <= 14 (S <= 16 rows in one lane, 1 + P = 5 + 2 n <= 64 columns in one wave) and
 // n = 15 .. 62 (rows across the lanes of a group, eight columns per lane, the columns of a replica cut into chunks: pk_sens_rows.hpp),
+// randmod n = 6, 7 (parity-eliminated inverse in registers serving eight columns per workgroup: pk_rand_sens.hpp),
 // randmod n <= 3 (2^n <= 8 coupled rows inverted in registers; 1 + P <= 16 columns) and n = 4, 5 (the inverse shared by the group in LDS)
 bool sens_available(int model, int n_sites) {
-  if (model == M_RAND) return n_sites <= 5;
+  if (model == M_RAND) return n_sites <= 7;
   return n_sites <= 62;
 }
 
@@ -20,6 +22,7 @@ hipError_t launch_sens(const SensArgs& a, int model, hipStream_t st) {
   if (model == M_DIST) return launch_sens_dist(a, st);
   if (model == M_SUCC) return launch_sens_succ(a, st);
   const int n = a.s.n_sites;
+  if (n >= 6) return launch_rand_sens(a, st);                        // 74 / 139 columns of 65 / 129 rows: chunks of eight columns per workgroup
   if (n == 1) return launch_sens_one<CubeSys<1>, 8>(a, st);          // 1 + P = 7
   if (n == 2) return launch_sens_one<CubeSys<2>, 16>(a, st);         // 10
   if (n == 3) return launch_sens_one<CubeSys<3>, 16>(a, st);         // 15

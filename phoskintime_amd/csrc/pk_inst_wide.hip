@@ -3,6 +3,7 @@
 #include "pk_rand_dense.hpp"
 #include "pk_rand_level.hpp"
 #include "pk_rand_parity.hpp"
+#include "pk_rand_sens.hpp"
 #include "pk_launch.hpp"
 #include <atomic>
 #include <cstdlib>
@@ -46,6 +47,13 @@ hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st) {
   else if (a.n_sites == 7) hipLaunchKernelGGL(rand_parity_kernel<7>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(7), st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+
+// forward sensitivities of randmod n = 6, 7: the parity-eliminated inverse serves eight columns per workgroup (pk_rand_sens.hpp)
+hipError_t launch_rand_sens(const SensArgs& a, hipStream_t st) {
+  if (a.s.n_sites == 6) return launch_rand_sens_one<6>(a, st);
+  if (a.s.n_sites == 7) return launch_rand_sens_one<7>(a, st);
+  return hipErrorInvalidValue;
 }
 
 bool rand_dense_available(int n_sites) {

@@ -83,7 +83,7 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     n_active integrations, each carrying its P tangents; exact derivative of the discrete solution) -- ``"fd"``: SciPy's '2-point'
     forward differences, one launch of n_active * P perturbed replicas on the throughput kernels, which is what the reference's
     curve_fit does call by call.  ``"auto"`` (default) takes "sens" where a kernel exists (``batch.sens_available``: distmod / succmod
-    n <= 14, randmod n <= 5) and the solver options are the default method's, else "fd".  Either way one more launch per damping round
+    n <= 62, randmod n <= 7) and the solver options are the default method's, else "fd".  Either way one more launch per damping round
     evaluates the trial points, ``trial_levels`` consecutive damping values (mu, 4 mu, 16 mu) per row and launch ("auto": three while at
     most 256 rows are pending, else one); the first acceptable one is taken, as a one-try-per-launch loop (``trial_levels=1``) would.
 

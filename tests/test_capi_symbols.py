@@ -36,7 +36,7 @@ def test_shapes(built_lib):
     assert built_lib.pk_protein_flat_len(0, 4, 3) == 0 + 3 + 12   # T <= 5: the R(t5..) block is empty
     assert built_lib.pk_protein_n_states(3, 4) < 0 and built_lib.pk_protein_n_states(0, 0) < 0
     # sizes with a forward-sensitivity kernel (csrc/pk_sens.hpp)
-    assert [built_lib.pk_protein_sens_available(m, n) for m, n in ((0, 1), (0, 14), (0, 15), (0, 62), (0, 63), (1, 62), (1, 63), (2, 5), (2, 6), (3, 1), (0, 0))] == [1, 1, 1, 1, 0, 1, 0, 1, 0, 0, 0]
+    assert [built_lib.pk_protein_sens_available(m, n) for m, n in ((0, 1), (0, 14), (0, 15), (0, 62), (0, 63), (1, 62), (1, 63), (2, 5), (2, 7), (2, 8), (3, 1), (0, 0))] == [1, 1, 1, 1, 0, 1, 0, 1, 1, 0, 0, 0]
 
 
 def test_default_opts_struct_layout(built_lib):

@@ -42,7 +42,9 @@ CASES = [("distmod", 1), ("distmod", 3), ("distmod", 4), ("distmod", 8), ("distm
          ("succmod", 1), ("succmod", 2), ("succmod", 5), ("succmod", 9), ("succmod", 14),
          # rows-per-lane kernel (csrc/pk_sens_rows.hpp): 32-lane groups up to 30 sites (BASELINE config 3's size), 64-lane groups to 62
          ("distmod", 15), ("distmod", 30), ("distmod", 31), ("distmod", 62), ("succmod", 15), ("succmod", 30), ("succmod", 47), ("succmod", 62),
-         ("randmod", 1), ("randmod", 2), ("randmod", 3), ("randmod", 4), ("randmod", 5)]
+         ("randmod", 1), ("randmod", 2), ("randmod", 3), ("randmod", 4), ("randmod", 5),
+         # parity-eliminated inverse serving eight columns per workgroup (csrc/pk_rand_sens.hpp): 74 / 139 columns of 65 / 129 rows
+         ("randmod", 6), ("randmod", 7)]
 
 
 @pytest.mark.parametrize("model,n", CASES)
@@ -50,7 +52,7 @@ def test_sensitivities_match_central_differences_of_the_oracle(eng, model, n):
     mid = pm.MODEL_IDS[model]
     S, P = pm.n_states(mid, n), pm.n_params(mid, n)
     rng = np.random.default_rng(100 * mid + n)
-    B = 5                                               # not a multiple of the replicas per wave: the last wave carries shadow groups
+    B = 5 if S <= 64 else 2                             # not a multiple of the replicas per wave: the last wave carries shadow groups
     th = rng.uniform(0.2, 2.0, size=(B, P))
     y0 = rng.uniform(0.3, 1.5, size=S)
     t = pm.TIME_POINTS
@@ -114,9 +116,9 @@ def test_sensitivities_follow_flat_postprocessing_and_batched_y0(eng):
 def test_sizes_without_a_sensitivity_kernel_are_refused(eng):
     from phoskintime_amd._capi import PhoskinError
     assert eng.sens_available("distmod", 62) and not eng.sens_available("distmod", 63) and eng.sens_available("succmod", 62) and not eng.sens_available("succmod", 63)
-    assert eng.sens_available("randmod", 5) and not eng.sens_available("randmod", 6)
+    assert eng.sens_available("randmod", 7) and not eng.sens_available("randmod", 8)
     with pytest.raises(PhoskinError):
-        eng.solve_ode_sens_batch("randmod", np.ones((1, pm.n_params(2, 6))), np.ones(pm.n_states(2, 6)), 6, pm.TIME_POINTS)
+        eng.solve_ode_sens_batch("randmod", np.ones((1, pm.n_params(2, 8))), np.ones(pm.n_states(2, 8)), 8, pm.TIME_POINTS)
     with pytest.raises(PhoskinError):
         eng.solve_ode_sens_batch("distmod", np.ones((1, pm.n_params(0, 63))), np.ones(65), 63, pm.TIME_POINTS)
     # failed replicas: flagged, NaN rows, the rest of the batch unaffected
@@ -222,7 +224,9 @@ def test_dropin_jacobian_callable_for_scipy_curve_fit(eng):
     assert np.max(np.abs(f(t, *popt) - target)) < 1e-6
     models.set_model("randmod")
     with pytest.raises(Exception):
-        models.solve_ode_jac(np.ones(pm.n_params(2, 6)), np.ones(pm.n_states(2, 6)), 6, t)      # no kernel at n = 6: loud, not silent
+        models.solve_ode_jac(np.ones(pm.n_params(2, 8)), np.ones(pm.n_states(2, 8)), 8, t)      # no kernel at n = 8: loud, not silent
+    fl6, J6 = models.solve_ode_jac(np.full(pm.n_params(2, 6), 0.7), np.ones(pm.n_states(2, 6)), 6, t)       # n = 6, 7: the chunked-column kernel of round 3
+    assert fl6.shape == (9 + 14 + 6 * 14,) and J6.shape == (fl6.size, pm.n_params(2, 6)) and np.isfinite(J6).all()
     models.set_model("distmod")
 
 
@@ -318,3 +322,42 @@ def test_rows_kernel_postprocessing_chunks_and_failures(eng):
     at_t0 = [T - 5] + [T - 5 + T + j * T for j in range(n)]                      # rows written before the first step: values at t0 (data)
     assert np.isnan(np.delete(d2[1], at_t0, axis=0)).all() and np.all(d2[1][at_t0] == 0.0)
     assert np.array_equal(d2[0], da[0]) and np.array_equal(d2[4], da[4])
+
+
+def test_randmod_n6_sensitivities_postprocessing_chunks_and_failures(eng):
+    """randmod n = 6 (P = 73: eleven chunks of seven columns, the last with three): normalisation, clipping, batched y0, replica
+    independence, a failed replica flagged by every chunk, and the log-space chain rule the fits use."""
+    rng = np.random.default_rng(6)
+    n, mid = 6, 2
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    B = 3
+    th = rng.uniform(0.2, 2.0, size=(B, P)); y0 = rng.uniform(0.5, 2.0, size=(B, S)); y0[:, 2] = -50.0
+    t = pm.TIME_POINTS
+    T = t.size
+    a = eng.solve_ode_sens_batch("randmod", th, y0, n, t)
+    b = eng.solve_ode_sens_batch("randmod", th, y0, n, t, normalize=True)
+    raw = eng.solve_ode_sens_batch("randmod", th, y0, n, t, clip_nonneg=False)
+    assert not a.status.cpu().numpy().any()
+    scale = np.concatenate([np.repeat(y0[:, :1], T - 5, axis=1), np.repeat(y0[:, 1:2], T, axis=1)] + [np.repeat(y0[:, 2 + j:3 + j], T, axis=1) for j in range(n)], axis=1)
+    fa, da = a.flat.cpu().numpy(), a.dflat.cpu().numpy()
+    np.testing.assert_allclose(b.flat.cpu().numpy() * scale, fa, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(b.dflat.cpu().numpy() * scale[:, :, None], da, rtol=1e-10, atol=1e-14)
+    fr, dr = raw.flat.cpu().numpy(), raw.dflat.cpu().numpy()
+    clipped = fr < 0.0
+    assert clipped.any() and np.all(fa[clipped] == 0.0) and np.all(da[clipped] == 0.0) and np.abs(dr[clipped]).max() > 0.0
+    np.testing.assert_array_equal(da[~clipped], dr[~clipped])
+    plain = eng.solve_ode_batch("randmod", th, y0, n, t, want_sol=False).flat.cpu().numpy()
+    assert np.max(np.abs(fa - plain) / (1e-8 + 1e-6 * np.abs(plain))) < 0.1
+    one = eng.solve_ode_sens_batch("randmod", th[1:2], y0[1:2], n, t)
+    assert np.array_equal(one.dflat.cpu().numpy()[0], da[1]) and np.array_equal(one.flat.cpu().numpy()[0], fa[1])
+    th2 = th.copy(); th2[2, 40] = np.nan
+    r = eng.solve_ode_sens_batch("randmod", th2, y0, n, t)
+    st = r.status.cpu().numpy()
+    assert st[2] != 0 and not st[:2].any() and np.array_equal(r.dflat.cpu().numpy()[0], da[0])
+    # the LM driver picks the kernel up: a log-space fit of a 6-site protein converges on exact Jacobians
+    from phoskintime_amd.paramest import fit_rows_batch
+    truth = rng.uniform(0.3, 1.5, P)
+    target = eng.solve_ode_batch("randmod", truth[None], np.ones(S), n, t, want_sol=False).flat.cpu().numpy()[0]
+    P0 = np.log(truth * np.exp(0.2 * rng.standard_normal((4, P))))
+    fit = fit_rows_batch("randmod", n, t, P0, np.ones(S), target, bounds=(np.full(P, np.log(1e-8)), np.full(P, np.log(20.0))), max_iter=40, jacobian="sens")
+    assert (fit.cost < 1e-5).all(), fit.cost            # 73 weakly identified parameters, 40 iterations: five decades below the start (cost ~ 1)
