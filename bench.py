@@ -482,14 +482,17 @@ def lm_leg():
         lb, ub = np.zeros(P), np.full(P, 20.0)
         P0 = multistart_candidates("BENCH", rng.uniform(lb, ub), lb, ub, n_starts=rows)
         leg = {"rows": rows, "P": P, "residuals": int(flat.size), "flat_bytes_per_jacobian": rows * P * flat.size * 8}
-        modes = [("device_algebra", True, "fd"), ("host_algebra_round1", False, "fd")]
+        modes = [("device_algebra", True, "fd", "auto"), ("host_algebra_round1", False, "fd", "host")]
         if batch.sens_available("distmod", n):
-            modes.insert(0, ("forward_sensitivities", "auto", "sens"))
-        for name, dev_alg, jac in modes:
-            fit_rows_batch("distmod", n, TGRID, P0[:4], np.ones(S), target, bounds=(lb, ub), max_iter=2, device_algebra=dev_alg, jacobian=jac)
+            modes.insert(0, ("forward_sensitivities", "auto", "sens", "auto"))
+            modes.insert(1, ("forward_sensitivities_host_lm_round2", "auto", "sens", "host"))
+        for name, dev_alg, jac, lm in modes:
+            fit_rows_batch("distmod", n, TGRID, P0[:4], np.ones(S), target, bounds=(lb, ub), max_iter=2, device_algebra=dev_alg, jacobian=jac, lm_algebra=lm)
+            if lm == "auto" and rows * P * P >= (1 << 17):                               # warm the batched-LU path at its real shape
+                fit_rows_batch("distmod", n, TGRID, P0, np.ones(S), target, bounds=(lb, ub), max_iter=1, device_algebra=dev_alg, jacobian=jac, lm_algebra=lm)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            fit = fit_rows_batch("distmod", n, TGRID, P0, np.ones(S), target, bounds=(lb, ub), max_iter=iters, device_algebra=dev_alg, jacobian=jac)
+            fit = fit_rows_batch("distmod", n, TGRID, P0, np.ones(S), target, bounds=(lb, ub), max_iter=iters, device_algebra=dev_alg, jacobian=jac, lm_algebra=lm)
             torch.cuda.synchronize()
             leg[name] = {"wall_ms": 1e3 * (time.perf_counter() - t1), "iterations": fit.n_iter, "solves": fit.n_solves, "launches": fit.n_launches,
                          "best_cost": float(fit.cost.min()), "median_cost": float(np.median(fit.cost))}

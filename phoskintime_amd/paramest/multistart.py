@@ -71,7 +71,7 @@ class RowsFit:
 
 def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, target, sigma=None, lam=0.0, bounds=None,
                    max_iter: int = 100, ftol: float = 1e-10, xtol: float = 1e-10, device_algebra="auto", jacobian="auto", trial_levels="auto",
-                   force_reg: Optional[bool] = None, **solver_kw) -> RowsFit:
+                   force_reg: Optional[bool] = None, lm_algebra="auto", **solver_kw) -> RowsFit:
     """R independent bounded least-squares problems in lockstep: row k fits ``[flat(p) ; lam_k / P * p**2]`` to ``[target_k ; 0]`` with
     weights ``sigma_k`` from the start point ``P0[k]``.  Rows may be the starts of one multistart fit, the (lambda, weight) grid of
     ``find_best_lambda``, bootstrap replicates, different proteins of the same size -- or any mix.
@@ -93,7 +93,15 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     ``"auto"`` (default) picks by the size of that transfer (> 2 MB: device).  Measured on MI355X (bench.py `lm_fit`): at 1 MB per Jacobian
     (48 starts, P = 20) the two paths tie (145-220 ms host, 183-186 ms device per 60-iteration fit: a dozen small torch launches and their
     synchronisations cost what the copy costs); at 109 MB (480 rows, P = 64: the lambda scan of a 30-site protein) the device path
-    takes 0.39 s against 3.4 s.  The P x P bounded Levenberg-Marquardt algebra itself is batched numpy on the host either way."""
+    takes 0.39 s against 3.4 s.
+
+    ``lm_algebra``: where the P x P damped normal equations of the trial steps are solved.  "host" (rounds 1-2): J^T J comes back (P x P per
+    row and iteration) and batched numpy does the masking, the solves and the predicted reductions -- measured with cProfile on the 480-row
+    lambda scan at P = 64 (tools/gpu_fit_profile2.py): 390 of the fit's 394 ms, against 10 ms of Jacobian kernels.  "device": J^T J stays in
+    HBM; masking, the damped solves of all damping levels (``torch.linalg.solve_ex``: the vendor's batched LU), the projection on the box
+    and the predicted reductions are device ops, and only vectors (gradient, diagonal, trial points' costs: O(P) per row) cross PCIe.
+    "auto": device when rows x P^2 >= 2^17 and the residual algebra is on the device, else host (small fits are launch-bound: a dozen
+    tiny device ops per round cost more than numpy on 48 x 12 x 12 numbers)."""
     import torch
     log_space = (model == "randmod")
     P0 = np.atleast_2d(np.asarray(P0, float))
@@ -122,6 +130,9 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     dev = torch.device("cuda", batch.get_context().device)
     if device_algebra == "auto":
         device_algebra = R * P * Nd * 8 > (2 << 20)                   # bytes of `flat` one Jacobian evaluation would move over PCIe
+    if lm_algebra not in ("auto", "host", "device"):
+        raise ValueError("lm_algebra must be 'auto', 'host' or 'device'")
+    lm_dev = (lm_algebra == "device") or (lm_algebra == "auto" and bool(device_algebra) and R * P * P >= (1 << 17))
     # per-fit constants go to HBM once (a host array handed to a launch is uploaded by that launch: 35 us each, several per iteration)
     t_d = torch.as_tensor(tfull, device=dev); isig_d = torch.as_tensor(1.0 / sig, device=dev); lam_d = torch.as_tensor(lam / P, device=dev)
     y0_d = torch.as_tensor(np.array(y0, dtype=float, copy=True), device=dev)
@@ -189,6 +200,7 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     mu = np.full(R, 1e-3)
     active = np.ones(R, bool)
     JTJ = np.zeros((R, P, P))
+    JTJ_d = torch.zeros((R, P, P), dtype=torch.float64, device=dev) if lm_dev else None
     it = 0
     for it in range(1, max_iter + 1):
         idx = np.where(active)[0]
@@ -206,26 +218,41 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
                 r_at = r_d[torch.as_tensor(idx, device=dev)]
             else:
                 r_at = torch.as_tensor(r[idx], device=dev)
-            # J^T [J | r] in one product, one copy back: [k, P, P + 1]
-            AG = torch.bmm(Jd.transpose(1, 2), torch.cat([Jd, r_at[:, :, None]], dim=2)).cpu().numpy()
-            A, g = np.ascontiguousarray(AG[:, :, :P]), np.ascontiguousarray(AG[:, :, P])
+            # J^T [J | r] in one product, one copy back: [k, P, P + 1]  (lm_algebra = device: only the gradient and the diagonal come back)
+            AG_d = torch.bmm(Jd.transpose(1, 2), torch.cat([Jd, r_at[:, :, None]], dim=2))
+            if lm_dev:
+                A_d, g_d = AG_d[:, :, :P].contiguous(), AG_d[:, :, P].contiguous()
+            else:
+                AG = AG_d.cpu().numpy()
+                A, g = np.ascontiguousarray(AG[:, :, :P]), np.ascontiguousarray(AG[:, :, P])
         elif device_algebra:
             idx_d = torch.as_tensor(idx, device=dev)
             rp = residuals_dev(torch.as_tensor(Pp, device=dev), idx_d.repeat_interleave(P)).reshape(idx.size, P, Nr)
             Jd = ((rp - r_d[idx_d][:, None, :]) / torch.as_tensor(h, device=dev)[:, :, None]).transpose(1, 2)        # [k, Nr, P]
-            A = torch.bmm(Jd.transpose(1, 2), Jd).cpu().numpy()                                                     # J^T J : [k, P, P]
-            g = torch.bmm(Jd.transpose(1, 2), r_d[idx_d][:, :, None])[:, :, 0].cpu().numpy()                        # J^T r : [k, P]
+            A_d = torch.bmm(Jd.transpose(1, 2), Jd)                                                                 # J^T J : [k, P, P]
+            g_d = torch.bmm(Jd.transpose(1, 2), r_d[idx_d][:, :, None])[:, :, 0]                                    # J^T r : [k, P]
+            if not lm_dev:
+                A, g = A_d.cpu().numpy(), g_d.cpu().numpy()
         else:
             rp = residuals(Pp, np.repeat(idx, P)).reshape(idx.size, P, Nr)
             Ja = np.transpose((rp - r[idx][:, None, :]) / h[:, :, None], (0, 2, 1))
             g = np.einsum("knp,kn->kp", Ja, r[idx])
             A = np.einsum("knp,knq->kpq", Ja, Ja)
-        JTJ[idx] = A
+        if lm_dev:
+            if jacobian != "sens" and not device_algebra:                              # host residual algebra with device LM algebra: upload once
+                A_d, g_d = torch.as_tensor(A, device=dev), torch.as_tensor(g, device=dev)
+            JTJ_d[torch.as_tensor(idx, device=dev)] = A_d
+            g = g_d.cpu().numpy()
+            diagA = torch.diagonal(A_d, dim1=1, dim2=2).cpu().numpy()
+            p_idx_d, lb_idx_d, ub_idx_d = (torch.as_tensor(np.ascontiguousarray(x[idx]), device=dev) for x in (p, lb, ub))
+        else:
+            JTJ[idx] = A
+            diagA = np.einsum("kpp->kp", A)
         free = ~(((p[idx] <= lb[idx]) & (g > 0)) | ((p[idx] >= ub[idx]) & (g < 0)))
         gfree = np.where(free, g, 0.0)
         done = (~free.any(axis=1)) | (np.linalg.norm(gfree, axis=1) < 1e-14 * np.maximum(1.0, cost[idx]))
         active[idx[done]] = False
-        DD = np.maximum(np.sqrt(np.einsum("kpp->kp", A)), 1e-12)                       # Marquardt scaling (the reference's x_scale='jac')
+        DD = np.maximum(np.sqrt(diagA), 1e-12)                                         # Marquardt scaling (the reference's x_scale='jac')
         pend = np.where(~done)[0]                                                      # positions inside idx
         # Levenberg-Marquardt trial steps, still in lockstep.  The sequential rule -- try mu; if the step is rejected, try 4 mu, 16 mu, ...
         # (up to 12 tries) -- is kept, but `trial_levels` consecutive damping values of every pending row are evaluated in ONE launch
@@ -243,10 +270,43 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
             rows = idx[pend]
             m = pend.size
             fr = free[pend]
-            Af0 = A[pend] * (fr[:, :, None] & fr[:, None, :])
-            rhs = -gfree[pend]
-            trials = np.empty((K, m, P))
-            for lv in range(K):
+            if lm_dev:
+                # the damped normal equations of all K levels, the projection on the box and the predicted reductions on the device
+                pend_d = torch.as_tensor(pend, device=dev)
+                fr_d = torch.as_tensor(fr, device=dev)
+                Ap_d = A_d[pend_d]
+                Af0_d = Ap_d * (fr_d[:, :, None] & fr_d[:, None, :])
+                rhs_d = torch.as_tensor(-gfree[pend], device=dev)
+                dg0_d = torch.as_tensor(np.where(fr, mu[rows, None] * DD[pend] ** 2, 0.0), device=dev)
+                one_fixed = (~fr_d).to(torch.float64)                                  # fixed variables: identity row, zero step
+                pr_d, lbr_d, ubr_d = p_idx_d[pend_d], lb_idx_d[pend_d], ub_idx_d[pend_d]
+                tl = []
+                for lv in range(K):
+                    Af = Af0_d.clone()
+                    Af.diagonal(dim1=1, dim2=2).add_(dg0_d * (4.0 ** lv) + one_fixed)
+                    step_d, _info = torch.linalg.solve_ex(Af, rhs_d[:, :, None])
+                    step_d = step_d[:, :, 0]
+                    step_d = torch.where(torch.isfinite(step_d), step_d, torch.zeros_like(step_d))
+                    tl.append(torch.minimum(torch.maximum(pr_d + step_d, lbr_d), ubr_d))
+                trials_d = torch.stack(tl)                                             # [K, m, P]
+                dp_d = trials_d - pr_d[None]
+                Adp = torch.matmul(Ap_d[None], dp_d[..., None])[..., 0]
+                pred_dv = -((g_d[pend_d][None] * dp_d).sum(dim=2) + 0.5 * (dp_d * Adp).sum(dim=2))
+                rows_d = torch.as_tensor(rows, device=dev)
+                if device_algebra:
+                    rn_d = residuals_dev(trials_d.reshape(K * m, P), rows_d.repeat(K)).reshape(K, m, Nr)
+                    cn = (0.5 * (rn_d * rn_d).sum(dim=2)).cpu().numpy()
+                trials = trials_d.cpu().numpy()
+                if not device_algebra:
+                    rn = residuals(trials.reshape(K * m, P), np.tile(rows, K)).reshape(K, m, Nr)
+                    cn = 0.5 * np.sum(rn * rn, axis=2)
+                dp = trials - p[rows][None]
+                pred = pred_dv.cpu().numpy()
+            trials = trials if lm_dev else np.empty((K, m, P))
+            if not lm_dev:
+                Af0 = A[pend] * (fr[:, :, None] & fr[:, None, :])
+                rhs = -gfree[pend]
+            for lv in range(0 if lm_dev else K):
                 Af = Af0.copy()
                 dg = np.where(fr, (mu[rows, None] * 4.0 ** lv) * DD[pend] ** 2, 1.0)   # fixed variables: identity row, zero step
                 Af[:, np.arange(P), np.arange(P)] += dg
@@ -261,15 +321,17 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
                             pass
                 step = np.where(np.isfinite(step), step, 0.0)
                 trials[lv] = np.clip(p[rows] + step, lb[rows], ub[rows])
-            if device_algebra:
-                rows_d = torch.as_tensor(rows, device=dev)
-                rn_d = residuals_dev(torch.as_tensor(trials.reshape(K * m, P), device=dev), rows_d.repeat(K)).reshape(K, m, Nr)
-                cn = (0.5 * (rn_d * rn_d).sum(dim=2)).cpu().numpy()                    # [K, m]
-            else:
-                rn = residuals(trials.reshape(K * m, P), np.tile(rows, K)).reshape(K, m, Nr)
-                cn = 0.5 * np.sum(rn * rn, axis=2)
-            dp = trials - p[rows][None]
-            pred = -(np.einsum("kp,lkp->lk", g[pend], dp) + 0.5 * np.einsum("lkp,kpq,lkq->lk", dp, A[pend], dp))
+            if not lm_dev:
+                if device_algebra:
+                    rows_d = torch.as_tensor(rows, device=dev)
+                    rn_d = residuals_dev(torch.as_tensor(trials.reshape(K * m, P), device=dev), rows_d.repeat(K)).reshape(K, m, Nr)
+                    cn = (0.5 * (rn_d * rn_d).sum(dim=2)).cpu().numpy()                # [K, m]
+                else:
+                    rn = residuals(trials.reshape(K * m, P), np.tile(rows, K)).reshape(K, m, Nr)
+                    cn = 0.5 * np.sum(rn * rn, axis=2)
+                dp = trials - p[rows][None]
+                Ap = A[pend]
+                pred = -(np.einsum("kp,lkp->lk", g[pend], dp) + 0.5 * np.einsum("lkp,lkp->lk", dp, np.matmul(Ap[None], dp[..., None])[..., 0]))
             rho = np.where(pred > 0, (cost[rows][None] - cn) / np.where(pred > 0, pred, 1.0), -1.0)
             okl = (cn < cost[rows][None]) & (rho > 1e-4)                                # [K, m]
             ok = okl.any(axis=0)
@@ -292,6 +354,8 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
             pend = pend[~ok]
         active[idx[pend]] = False          # no acceptable step within the damping budget: converged / stalled
     r_out = r_d.cpu().numpy() if device_algebra else r
+    if lm_dev:
+        JTJ = JTJ_d.cpu().numpy()
     return RowsFit(p=p, cost=cost, r=r_out, JTJ=JTJ, n_iter=it, n_solves=n_solves, n_launches=n_launches)
 
 

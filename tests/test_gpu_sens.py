@@ -179,6 +179,33 @@ def test_batched_damping_levels_take_the_same_steps_as_one_try_per_launch(eng):
     assert b.n_launches <= a.n_launches and b.n_solves >= a.n_solves
 
 
+def test_lm_algebra_on_the_device_takes_the_steps_of_the_host_algebra(eng):
+    """`lm_algebra` = "device" (damped normal equations of all levels by the vendor's batched LU, projection and predicted reductions in HBM)
+    against "host" (batched numpy, rounds 1-2): with the sensitivity Jacobian the iterates agree to the rounding of two different LU codes
+    -- including rows that sit on a bound (free-set masking) and rounds whose first tries are rejected."""
+    from phoskintime_amd.paramest import multistart as ms
+    model, n = "distmod", 20
+    mid = pm.MODEL_IDS[model]
+    S, P = pm.n_states(mid, n), pm.n_params(mid, n)
+    rng = np.random.default_rng(7)
+    truth = rng.uniform(0.3, 1.5, size=P)
+    y0 = np.ones(S); t = pm.TIME_POINTS
+    target = eng.solve_ode_batch(model, truth[None], y0, n, t, want_sol=False).flat.cpu().numpy()[0]
+    target = np.abs(target * (1.0 + 0.02 * rng.standard_normal(target.size)))
+    lb, ub = np.zeros(P), np.full(P, 2.0)                            # a tight box: several variables end on it
+    P0 = np.clip(truth * rng.uniform(0.2, 4.0, size=(40, P)), lb, ub)
+    kw = dict(bounds=(lb, ub), max_iter=6, jacobian="sens", device_algebra=True)
+    a = ms.fit_rows_batch(model, n, t, P0, y0, target, lm_algebra="host", **kw)
+    b = ms.fit_rows_batch(model, n, t, P0, y0, target, lm_algebra="device", **kw)
+    assert ((a.p == lb) | (a.p == ub)).any()
+    np.testing.assert_allclose(a.p, b.p, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(a.cost, b.cost, rtol=1e-6, atol=1e-14)
+    np.testing.assert_allclose(a.JTJ, b.JTJ, rtol=1e-5, atol=1e-9 * np.abs(a.JTJ).max())
+    assert a.n_solves == b.n_solves
+    with pytest.raises(ValueError):
+        ms.fit_rows_batch(model, n, t, P0, y0, target, lm_algebra="gpu", **kw)
+
+
 def test_sensitivity_edge_shapes(eng):
     """T = 1 (only the initial time: flat is data, zero Jacobian), T <= 5 (no R block in flat), B = 0, one replica, batched y0 at randmod n = 4."""
     import torch

@@ -105,3 +105,32 @@ def test_large_network_rhs_bit_exact(f):
     # the reference's optimiser-tolerance run (1e-8) against its own 1e-12 run: the error the parity band has to live with
     band = np.max(np.abs(g["Y_lsoda8"][0] - g["Y_tight"][0]) / (1e-8 + 1e-6 * np.abs(g["Y_tight"][0])))
     assert band < 5.0
+
+
+MORE = sorted((Path(__file__).resolve().parent / "golden").glob("netlarge_more_m[0-9].npz"))
+
+
+def test_large_network_more_reference_runs_inventory():
+    """tools/make_golden_network.py large_more: further parameter sets of the SAME four N = 100 networks, each integrated by the reference at
+    1e-12 -- the truth the GPU population tests compare with (written candidate by candidate, so the count may differ per topology)."""
+    assert [f.name for f in MORE] == [f"netlarge_more_m{m}.npz" for m in (0, 1, 2, 4)]
+    for f in MORE:
+        q = np.load(f); g = np.load(f.parent / f"netlarge_m{int(q['model'])}.npz")
+        K = int(q["done"])
+        assert K >= 3 and q["Y_tight"].shape == (K, 15, int(g["S"])) and np.isfinite(q["Y_tight"]).all()
+        np.testing.assert_array_equal(q["y0"], g["y0"]); np.testing.assert_array_equal(q["t_eval"], g["t_eval"])
+        for k in range(K):
+            np.testing.assert_array_equal(q["Y_tight"][k, 0], g["y0"])
+        # candidate 0 is the fixture's second parameter set (the one that had only a 1e-8 run): same parameters, and its 1e-8 run agrees
+        assert int(q["from_netlarge_index"][0]) == 1
+        for key in ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i", "tf_scale"):
+            np.testing.assert_array_equal(q[key][0], g[key][1])
+            assert q[key].shape[0] == K
+        band = np.max(np.abs(g["Y_lsoda8"][1] - q["Y_tight"][0]) / (1e-8 + 1e-6 * np.abs(q["Y_tight"][0])))
+        assert band < 5.0
+        # the oracle's RHS restatement takes these parameter sets (shapes of the same network) and is finite at the start
+        net = nm.Network.from_npz(g)
+        for k in range(K):
+            p = nm.Params.from_npz(q, k)
+            f0 = nm.rhs(net, p, q["Y_tight"][k, 0], float(q["t_eval"][0]))
+            assert np.isfinite(f0).all()
