@@ -10,7 +10,9 @@ static int site_class(int max_sites) { return max_sites <= 4 ? 4 : max_sites <= 
 // rows of a block vector: 2 + site class (topologies 0 / 1 / 4), 1 + 2^NB with NB = 2 or 3 (combinatorial)
 size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads) {
   const int rows = n.model == 2 ? 1 + (max_sites <= 2 ? 4 : 8) : 2 + site_class(max_sites);
-  return net_solve_ark_lds_bytes(n, nnzT, rows, threads);
+  // PK_ARK_LDS_PAD (bytes, dev switch, read once): unused LDS per workgroup, to measure the kernel at fewer resident workgroups per CU
+  static const size_t pad = [] { const char* v = getenv("PK_ARK_LDS_PAD"); return v ? (size_t)atol(v) : (size_t)0; }();
+  return net_solve_ark_lds_bytes(n, nnzT, rows, threads) + pad;
 }
 
 template <int M, int MS>

@@ -14,6 +14,9 @@ namespace pk {
 // order-4 additive integrator (pk_network_solve_ark.hpp), its own translation unit: returns the dynamic LDS it needs, or launches
 size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads);
 hipError_t launch_net_ark(const NetDev& n, const NetSolveArgs& a, int max_sites, long long B, int threads, size_t lds, hipStream_t st);
+// the same method in the dense two-lanes-per-protein layout (pk_network_solve_arkp.hpp; arrow topologies): n.lane_unit must be set
+bool net_arkp_enabled();
+hipError_t launch_net_arkp(const NetDev& n, const NetSolveArgs& a, int nnzT, int max_sites, long long B, hipStream_t st);
 }
 #include <algorithm>
 #include <cstdlib>
@@ -161,6 +164,18 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
   n->max_sites = 0;
   for (int i = 0; i < d->N; ++i) n->max_sites = std::max(n->max_sites, (int)d->n_sites[i]);
   n->kin_grid_host.assign(d->kin_grid, d->kin_grid + d->n_grid);
+  v.lane_unit = nullptr; v.n_lanes = 0;
+  if ((d->model == 0 || d->model == 4) && n->max_sites <= 8) {
+    // dense lane table: a lane holds (2 + site class) / 2 rows; proteins with more sites than fit beside mRNA and protein take a second lane
+    const int cls = n->max_sites <= 4 ? 4 : n->max_sites <= 6 ? 6 : 8, nrl = (2 + cls) / 2;
+    std::vector<int32_t> lanes;
+    // ... and so do proteins with more than 4 regulators: the lanes of a pair split the TF row, 4 register-resident entries each
+    auto two = [&](int i) { return d->n_sites[i] > nrl - 2 || d->TF_indptr[i + 1] - d->TF_indptr[i] > 4; };
+    for (int i = 0; i < d->N; ++i) if (two(i)) { lanes.push_back((i << 2) | 2); lanes.push_back((i << 2) | 3); }
+    for (int i = 0; i < d->N; ++i) if (!two(i)) lanes.push_back(i << 2);
+    v.n_lanes = (int)lanes.size();
+    v.lane_unit = upload(n, lanes.data(), lanes.size(), ok);
+  }
   if (!ok || n->lds_bytes > 160 * 1024) {
     pk_ctx_fail(c, ok ? PK_ERR_UNSUPPORTED : PK_ERR_NOMEM, ok ? "network too large for one workgroup's LDS (160 KiB)" : "hipMalloc / hipMemcpy failed");
     pk_network_destroy(n);
@@ -339,7 +354,10 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
       static const double ctl_s = [] { const char* v = getenv("PK_ARK_SAFETY"); return v ? atof(v) : 0.0; }();      // dev knobs of the controller
       static const double ctl_g = [] { const char* v = getenv("PK_ARK_GROW"); return v ? atof(v) : 0.0; }();
       aa.ctl_safety = ctl_s; aa.ctl_grow = ctl_g;
-      hipError_t ea = pk::launch_net_ark(n->d, aa, n->max_sites, (long long)B, threads_a, lds_a, stream);
+      // [r3] arrow topologies: the dense two-lanes-per-protein layout, every stage vector in registers (PK_ARK_PAIR=0: round 2's kernel)
+      const bool pair = n->d.lane_unit && n->d.n_lanes <= 512 && pk::net_arkp_enabled();
+      hipError_t ea = pair ? pk::launch_net_arkp(n->d, aa, n->nnzT, n->max_sites, (long long)B, stream)
+                           : pk::launch_net_ark(n->d, aa, n->max_sites, (long long)B, threads_a, lds_a, stream);
       if (ea == hipSuccess) ea = hipGetLastError();
       return ea == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(ea));
     }

@@ -1,0 +1,325 @@
+// pk_network_solve_arkp.hpp -- [r3] the order-4 additive network integrator (ARK4(3)6L[2]SA, pk_network_solve_ark.hpp) in a DENSE lane
+// layout: arrow topologies (distributive 0, saturating 4), a protein's block split over at most TWO adjacent lanes.
+//
+// Why: round 2's kernel (one thread per protein, 2 + MAXS rows each) is latency-bound, not issue-bound.  Measured on config 5 (8 192
+// candidates, N = 100, <= 6 sites; tools/gpu_net5_time.py with PK_ARK_LDS_PAD): 149.6 / 189.7 / 270.7 / 503.1 ms at 4 / 3 / 2 / 1 resident
+// workgroups per CU -- throughput is proportional to the waves in flight; a lone workgroup spends ~4 000 clocks per stage of which ~750
+// issue VALU work.  Its 8-row block vectors fill all 256 VGPRs (28 spilled) AND need 32 KB of LDS for the stage right-hand sides R_3..R_6,
+// whose load -> fma -> store chains (75 LDS operations, 40 s_waitcnt per stage; ds_write_b64 costs ~6 clocks each) are the exposed latency.
+//
+// Here a lane owns NRL = (2 + site class) / 2 rows: lane A = [mRNA, protein, first NRL - 2 sites], lane B = [the next NRL sites].
+// Proteins with <= NRL - 2 sites take ONE lane (no idle partner): N = 100 with 1..6 sites -> ~167 lanes = 3 waves, against the 2 waves x 8
+// rows (28 idle lanes, 31 % zero rows) before.  Half the rows per lane -> every block vector of the method (y, Y, hF, hG, g r, both running
+// sums AND the four parked right-hand sides) lives in registers: no LDS round trip left in a stage but the TF gather of P_vec.
+// The arrow structure needs two exchanges per solve / product between the lanes of a pair (sum of the site terms: quad_perm [1,0,3,2];
+// the protein row's value: quad_perm [0,0,2,2]) -- 2 DPP moves each, VALU only.
+//
+// Same arithmetic as net_solve_ark_kernel up to the order of the site sums; same controller, stops, status and output conventions.
+#pragma once
+#include "pk_network_solve_ark.hpp"
+
+namespace pk {
+
+// lane table entry: (protein << 2) | (paired << 1) | half.  Pairs sit on (even, odd) lanes, single-lane proteins after them.
+__host__ __device__ constexpr int arkp_rows_per_lane(int site_class) { return (2 + site_class) / 2; }
+
+template <int MODEL, int NRL>
+__global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, const NetSolveArgs A) {
+  using namespace ark436;
+  static_assert(MODEL == 0 || MODEL == 4, "arrow topologies only");
+  extern __shared__ __align__(16) double lds[];
+  const int N = n.N, S = n.S;
+  double* Kt = lds;                       // [n_K]
+  double* Pv = Kt + n.n_K;                // [2][N]
+  double* red = Pv + 2 * N;               // [24]
+  const int nnzT = n.TF_indptr[N];
+  double* tf_dat = red + 24;              // [nnzT]
+  int32_t* tf_idx = reinterpret_cast<int32_t*>(tf_dat + nnzT);
+  const NetSlices sl(n.n_K, N, n.sites);
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const bool own = tid < n.n_lanes;
+  const int unit = own ? n.lane_unit[tid] : 0;
+  const int i = unit >> 2;
+  const bool paired = own && (unit & 2), hb = own && (unit & 1), la = own && !(unit & 1);      // hb: second lane of a pair; la: lane A (or single)
+  const double* stops = A.stops_p ? A.stops_p : A.stops_v;
+  const int32_t* stop_out = A.stop_out_p ? A.stop_out_p : A.stop_out_v;
+  const double* xb = A.x + b * n.n_var;
+  auto par = [&](int off) __attribute__((always_inline)) { const double v = xb[off]; return A.x_is_raw ? softplus(v) : v; };
+  for (int k = tid; k < nnzT; k += nt) { tf_dat[k] = n.TF_data[k]; tf_idx[k] = n.TF_indices[k]; }
+
+  const int st = own ? n.offset_y[i] : 0, ss = own ? n.offset_s[i] : 0, ns = own ? n.n_sites[i] : 0, drv = la ? n.driver_map[i] : -1;
+  // TF row of the protein: the lanes of a pair take alternate entries; the first TFC entries of a lane live in registers (static topology),
+  // so the gather of P_vec is TFC independent LDS reads -- the serial index -> value chain of a CSR loop (two LDS latencies per entry, up
+  // to 9 entries) was the longest dependent chain of a stage
+  constexpr int TFC = 4;
+  const int tfs = paired ? 2 : 1, tfb = own ? n.TF_indptr[i] + (hb ? 1 : 0) : 0, tf1 = own ? n.TF_indptr[i + 1] : 0;
+  int tix[TFC]; double tdt[TFC];
+#pragma unroll
+  for (int c = 0; c < TFC; ++c) {
+    const int e = tfb + c * tfs;
+    const bool ok = e < tf1;
+    tix[c] = ok ? n.TF_indices[e] : 0; tdt[c] = ok ? n.TF_data[e] : 0.0;
+  }
+  const int tf0 = tfb + TFC * tfs;                    // remainder (rare): from the LDS copy of the CSR arrays
+  const double tfdeg_inv = la ? 1.0 / n.tf_deg[i] : 1.0;
+  const double Ai = la ? par(sl.A + i) : 0.0, Bi = la ? par(sl.B + i) : 1.0, Ci = la ? par(sl.C + i) : 0.0, Di = own ? par(sl.D + i) : 1.0,
+               Ei = own ? par(sl.E + i) : 0.0, ts = par(sl.tf);
+  // rows of this lane: site index (or -1), loss coefficient E + Dp + D of a site row, validity
+  int sj[NRL]; bool valid[NRL]; double Lk[NRL], Sr[NRL];
+#pragma unroll
+  for (int k = 0; k < NRL; ++k) {
+    const int j = hb ? (NRL - 2 + k) : (k - 2);
+    const bool site = own && j >= 0 && j < ns;
+    sj[k] = site ? j : -1;
+    valid[k] = site || (la && k < 2);
+    Lk[k] = site ? Ei + par(sl.Dp + ss + j) + Di : 0.0;
+    Sr[k] = 0.0;
+  }
+  auto yoff = [&](int k) __attribute__((always_inline)) { return st + ((la && k < 2) ? k : 2 + sj[k]); };
+  const double* y0 = A.y0 + (A.y0_batched ? b * S : 0);
+  double* Yout = A.Y + b * (size_t)A.T * S;
+  double y[NRL];
+#pragma unroll
+  for (int k = 0; k < NRL; ++k) y[k] = valid[k] ? y0[yoff(k)] : 0.0;
+  auto write_row = [&](int row) __attribute__((always_inline)) {
+    double* o = Yout + (size_t)row * S;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) if (valid[k]) o[yoff(k)] = y[k];
+  };
+  write_row(0);
+
+  // pair exchanges (executed by every lane, convergently): sum over the two lanes of a protein; lane A's value seen by both lanes
+  auto pair_sum = [&](double v) __attribute__((always_inline)) { const double o = dpp_mov<0xB1>(v); return paired ? v + o : v; };
+  auto from_a = [&](double v) __attribute__((always_inline)) { const double o = dpp_mov<0xA0>(v); return hb ? o : v; };
+
+  double sumS = 0.0;
+  auto set_bucket = [&](const int jb) __attribute__((always_inline)) {
+    __syncthreads();
+    for (int k = tid; k < n.n_K; k += nt) Kt[k] = n.kin_Kmat[(size_t)k * n.n_grid + jb] * (A.x_is_raw ? softplus(xb[sl.ck + k]) : xb[sl.ck + k]);
+    __syncthreads();
+    double acc_all = 0.0;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+      double acc = 0.0;
+      if (sj[k] >= 0) for (int q = n.W_indptr[ss + sj[k]]; q < n.W_indptr[ss + sj[k] + 1]; ++q) acc += n.W_data[q] * Kt[n.W_indices[q]];
+      Sr[k] = acc; acc_all += acc;
+    }
+    sumS = pair_sum(acc_all);
+  };
+
+  // frozen block Jacobian of the step (entries that depend on y_n) and the factors of g I - A
+  double cRv = 0.0, gPv = 1.0, winvR = 1.0, sinv = 1.0, wv[NRL], cw[NRL];
+  int buf = 0;
+  // f(Y) of the block -> f; with MATVEC also G = A Y (stage 1: Y = y_n).  One barrier.
+  auto rhs_block = [&](const double (&Y)[NRL], double (&f)[NRL], double (&G)[NRL], auto mv) __attribute__((always_inline)) {
+    constexpr bool MATVEC = decltype(mv)::value;
+    double part = 0.0;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) part += (k >= 2 || hb) ? Y[k] : 0.0;
+    const double stot = pair_sum(part);                 // sum of the protein's phospho states
+    const double Pb = from_a(Y[1]);                     // its protein state, in both lanes
+    if (la) Pv[buf * N + i] = (drv >= 0) ? Kt[drv] : Y[1] + stot;
+    __syncthreads();
+    const double* Pb_ = Pv + buf * N;
+    double pv[TFC];
+#pragma unroll
+    for (int c = 0; c < TFC; ++c) pv[c] = Pb_[tix[c]];
+    if constexpr (TFC == 4) asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]));      // all reads in flight before the first use
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < TFC; ++c) acc = __builtin_fma(tdt[c], pv[c], acc);
+    for (int e = tf0; e < tf1; e += tfs) acc += tf_dat[e] * Pb_[tf_idx[e]];                              // degree > TFC per lane: rare (host pairs by degree)
+    acc = pair_sum(acc);
+    buf ^= 1;
+    // synthesis rate (calculate_synthesis_rate on the squashed TF input; models 0 / 1 / 2 squash twice: s(s(v)) = v / (1 + 2 |v|)), with ONE
+    // reciprocal chain per squash / rate instead of one per branch: den = 1 + u + 1e-6 (u >= 0) or 1 + ts |u| (u < 0)
+    const double v0 = acc * tfdeg_inv;
+    const double u = v0 * net_rcp(1.0 + (MODEL != 4 ? 2.0 : 1.0) * fabs(v0));
+    const bool pos = u >= 0.0;
+    const double rden = net_rcp(pos ? 1.0 + u + 1e-6 : __builtin_fma(ts, fabs(u), 1.0));
+    const double synth = pos ? Ai * __builtin_fma(ts * u, rden, 1.0) : Ai * rden;
+    const double fR = synth - Bi * Y[0];
+    double q = Pb, fP;
+    if (MODEL == 4) {
+      q = Pb * net_rcp(1.0 + Pb);
+      fP = (Ci * Y[0]) * net_rcp(1.0 + Y[0]) - Di * Y[1] - sumS * q + Ei * stot;
+    } else {
+      fP = Ci * Y[0] - (Di + sumS) * Y[1] + Ei * stot;
+    }
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+      const double fs = Sr[k] * q - Lk[k] * Y[k];
+      f[k] = (k == 0 && la) ? fR : (k == 1 && la) ? fP : fs;
+    }
+    if constexpr (MATVEC) {
+      const double sumSg = sumS * gPv;
+      const double gP_ = cRv * Y[0] - (Di + sumSg) * Y[1] + Ei * stot;
+#pragma unroll
+      for (int k = 0; k < NRL; ++k) {
+        const double gs = (Sr[k] * gPv) * Pb - Lk[k] * Y[k];
+        G[k] = (k == 0 && la) ? -Bi * Y[0] : (k == 1 && la) ? gP_ : gs;
+      }
+    }
+  };
+  auto freeze_factor = [&](const double g) __attribute__((always_inline)) {
+    const bool sat = MODEL == 4;
+    const double Pb = from_a(y[1]);
+    gPv = sat ? net_rcp((1.0 + Pb) * (1.0 + Pb)) : 1.0;
+    cRv = sat ? Ci * net_rcp((1.0 + y[0]) * (1.0 + y[0])) : Ci;
+    winvR = net_rcp(g + Bi);
+    double part = 0.0;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {                     // Sr = 0 on the mRNA / protein rows: they drop out of the sums by themselves
+      const double w = net_rcp(g + Lk[k]);
+      wv[k] = w; cw[k] = (Sr[k] * gPv) * w; part += Ei * cw[k];
+    }
+    sinv = net_rcp(g + Di + sumS * gPv - pair_sum(part));
+  };
+  // x = (g I - A)^-1 r
+  auto block_solve = [&](const double (&r)[NRL], double (&x)[NRL]) __attribute__((always_inline)) {
+    const double xR = r[0] * winvR;
+    double t[NRL], part = 0.0;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) { t[k] = r[k] * wv[k]; part += (k >= 2 || hb) ? Ei * t[k] : 0.0; }
+    const double xP = (r[1] + cRv * xR + pair_sum(part)) * sinv;          // meaningful in lane A
+    const double xPb = from_a(xP);
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+      const double xs = __builtin_fma(cw[k], xPb, t[k]);
+      x[k] = (k == 0 && la) ? xR : (k == 1 && la) ? xP : xs;
+    }
+  };
+
+  __syncthreads();
+  int status = PK_ST_OK, nacc = 0, nrej = 0;
+  double tc = A.t0;
+  int jb = net_bucket(tc, n.kin_grid, n.n_grid);
+  set_bucket(jb);
+  double h;
+  {
+    double f[NRL], dummy[NRL];
+    rhs_block(y, f, dummy, std::false_type{});
+    auto q = [&](double v, double yv) { return fabs(v) / (A.atol + A.rtol * fabs(yv)); };
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) if (valid[k]) { d0 = fmax(d0, q(y[k], y[k])); d1 = fmax(d1, q(f[k], y[k])); }
+    d0 = block_max(d0, red); d1 = block_max(d1, red);
+    h = (d0 > 1e-5 && d1 > 1e-5) ? 0.01 * d0 / d1 : 1e-6;
+    if (A.h0 > 0.0) h = A.h0;
+    if (!(h > 0.0) || h != h) h = 1e-6;
+  }
+  const bool rms = A.err_rms;
+  const double safety_inv = 1.0 / (A.ctl_safety > 0.0 ? A.ctl_safety : 0.9), grow_inv = 1.0 / (A.ctl_grow > 1.0 ? A.ctl_grow : 6.0);
+  bool after_reject = false;
+  for (int si = 0; si < A.n_stops && status == PK_ST_OK; ++si) {
+    const double te = stops[si];
+    while (true) {
+      if (nacc + nrej >= A.max_steps) { status |= PK_ST_MAXSTEPS; break; }
+      const bool last = (tc + 1.0001 * h >= te);
+      const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
+      if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; break; }
+      const double g = net_rcp(hs * GAM);
+      freeze_factor(g);
+      double Y[NRL], w[NRL], v[NRL], R[4][NRL], sb[NRL], se[NRL];
+      // ---- stage 1: Y_1 = y_n
+      rhs_block(y, w, v, std::true_type{});
+#pragma unroll
+      for (int k = 0; k < NRL; ++k) {
+        w[k] *= hs; v[k] *= hs;
+        sb[k] = B[0] * w[k]; se[k] = EB[0] * w[k];
+      }
+      static_for<4>([&](auto ic) {
+        constexpr int ii = decltype(ic)::value;                              // R_{ii + 3}
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) R[ii][k] = y[k] + AE[ii + 1][0] * w[k] + DI[ii + 1][0] * v[k];
+      });
+      // ---- stages 2 .. 6
+      static_for<5>([&](auto sc) {
+        constexpr int s = 2 + decltype(sc)::value;
+        double gr[NRL];                                                      // g * r_s
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+          double rk;
+          if constexpr (s == 2) rk = y[k] + AE[0][0] * w[k] + DI[0][0] * v[k]; else rk = R[s - 3][k];
+          gr[k] = g * rk;
+        }
+        block_solve(gr, Y);
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) v[k] = __builtin_fma(-hs, gr[k], (1.0 / GAM) * Y[k]);      // h G_s = (Y_s - r_s) / gamma
+        rhs_block(Y, w, gr, std::false_type{});
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+          w[k] *= hs;
+          if constexpr (s != 2) { sb[k] = __builtin_fma(B[s - 1], w[k], sb[k]); se[k] = __builtin_fma(EB[s - 1], w[k], se[k]); }
+        }
+        static_for<4>([&](auto ic) {
+          constexpr int ii = decltype(ic)::value;
+          if constexpr (ii + 3 > s) {
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) R[ii][k] = R[ii][k] + AE[ii + 1][s - 1] * w[k] + DI[ii + 1][s - 1] * v[k];
+          }
+        });
+      });
+      // ---- new value and error estimate
+      auto q = [&](double ev, double ya, double yb) { return fabs(ev) * net_rcp(A.atol + A.rtol * fmax(fabs(ya), fabs(yb))); };
+      double e = 0.0;
+#pragma unroll
+      for (int k = 0; k < NRL; ++k) {
+        sb[k] += y[k];                                                       // y_{n+1}
+        if (valid[k]) e = err_acc(e, q(se[k], y[k], sb[k]), rms);
+      }
+      const double err = err_reduce(e, rms, S, red);
+      if (err != err || err > 1e300) {
+        ++nrej; after_reject = true; h = 0.1 * hs;
+        double bad = (nonfinite(Ai) || nonfinite(Bi) || nonfinite(Ci) || nonfinite(Di) || nonfinite(Ei) || nonfinite(ts)) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) if (nonfinite(y[k]) || nonfinite(Lk[k]) || nonfinite(Sr[k])) bad = 1.0;
+        if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
+        continue;
+      }
+      double fac = sqrt(sqrt(err)) * safety_inv;                             // embedded order 3: err^(1/4)
+      fac = fmax(grow_inv, fmin(5.0, fac));
+      double hnew = hs * net_rcp(fac);
+      if (err <= 1.0) {
+        ++nacc;
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) y[k] = sb[k];
+        tc += hs;
+        if (after_reject) hnew = fmin(hnew, hs);
+        after_reject = false;
+        if (last) { tc = te; h = (hs < h) ? fmax(hnew, h) : hnew; break; }
+        h = hnew;
+      } else {
+        ++nrej; after_reject = true;
+        h = hnew;
+      }
+    }
+    if (status != PK_ST_OK) break;
+    const int row = stop_out[si];
+    if (row >= 0) write_row(row);
+    const int jn = net_bucket(tc, n.kin_grid, n.n_grid);
+    if (jn != jb) { jb = jn; set_bucket(jb); }
+  }
+  if (status != PK_ST_OK) {
+    const double qnan = __builtin_nan("");
+    for (int si = 0; si < A.n_stops; ++si) {
+      const int row = stop_out[si];
+      if (row >= 0 && !(stops[si] <= tc)) {
+        double* o = Yout + (size_t)row * S;
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) if (valid[k]) o[yoff(k)] = qnan;
+      }
+    }
+  }
+  if (tid == 0) {
+    if (A.status) A.status[b] = status;
+    if (A.n_steps) { A.n_steps[2 * b] = nacc; A.n_steps[2 * b + 1] = nrej; }
+  }
+}
+
+__host__ inline size_t net_solve_arkp_lds_bytes(const NetDev& n, int nnzT) {
+  return ((size_t)n.n_K + 2 * (size_t)n.N + 24 + nnzT + (nnzT + 1) / 2) * 8;
+}
+
+}  // namespace pk
