@@ -22,9 +22,13 @@ namespace pk {
 
 // lane table entry: (protein << 2) | (paired << 1) | half.  Pairs sit on (even, odd) lanes, single-lane proteins after them.
 __host__ __device__ constexpr int arkp_rows_per_lane(int site_class) { return (2 + site_class) / 2; }
+__host__ __device__ constexpr int arkp_park_stride(int rows_per_lane) { return (5 * rows_per_lane) | 1; }      // doubles per thread, odd
 
-template <int MODEL, int NRL>
-__global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, const NetSolveArgs A) {
+// PARK: per-row constants (loss coefficient, site rate, the two solve factors) and the two right-hand sides that are needed last (R_5, R_6)
+// live in LDS, thread-private [slot][thread]; the step-size scalars are moved to SGPRs.  That is the register diet for 3 waves per SIMD
+// (168 VGPRs): 4 workgroups of 3 waves per CU instead of 2, every SIMD equally loaded.
+template <int MODEL, int NRL, bool PARK>
+__device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSolveArgs& A) {
   using namespace ark436;
   static_assert(MODEL == 0 || MODEL == 4, "arrow topologies only");
   extern __shared__ __align__(16) double lds[];
@@ -32,9 +36,18 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
   double* Kt = lds;                       // [n_K]
   double* Pv = Kt + n.n_K;                // [2][N]
   double* red = Pv + 2 * N;               // [24]
-  const int nnzT = n.TF_indptr[N];
-  double* tf_dat = red + 24;              // [nnzT]
-  int32_t* tf_idx = reinterpret_cast<int32_t*>(tf_dat + nnzT);
+  // PARK: [thread][slot] with an ODD slot count per thread: one address VGPR + immediate offsets for any block size, and the lanes of a
+  // ds_read_b64 / ds_write_b64 group fall on distinct banks (2 * odd * lane mod 64)
+  constexpr int P_LK = 0, P_SR = NRL, P_WV = 2 * NRL, P_R5 = 3 * NRL, P_R6 = 4 * NRL, P_STRIDE = arkp_park_stride(NRL);
+  double* const mypark = red + 24 + (size_t)threadIdx.x * P_STRIDE;
+  auto pld = [&](int slot) __attribute__((always_inline)) { return mypark[slot]; };
+  auto pst = [&](int slot, double x) __attribute__((always_inline)) { mypark[slot] = x; };
+  auto uni = [](double x) __attribute__((always_inline)) {              // a block-uniform value into SGPRs
+    if constexpr (!PARK) return x;
+    else return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+  };
+  const double* tf_dat = n.TF_data;       // rows beyond the register-resident entries (rare): straight from HBM / L2
+  const int32_t* tf_idx = n.TF_indices;
   const NetSlices sl(n.n_K, N, n.sites);
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -46,7 +59,6 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
   const int32_t* stop_out = A.stop_out_p ? A.stop_out_p : A.stop_out_v;
   const double* xb = A.x + b * n.n_var;
   auto par = [&](int off) __attribute__((always_inline)) { const double v = xb[off]; return A.x_is_raw ? softplus(v) : v; };
-  for (int k = tid; k < nnzT; k += nt) { tf_dat[k] = n.TF_data[k]; tf_idx[k] = n.TF_indices[k]; }
 
   const int st = own ? n.offset_y[i] : 0, ss = own ? n.offset_s[i] : 0, ns = own ? n.n_sites[i] : 0, drv = la ? n.driver_map[i] : -1;
   // TF row of the protein: the lanes of a pair take alternate entries; the first TFC entries of a lane live in registers (static topology),
@@ -64,7 +76,7 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
   const int tf0 = tfb + TFC * tfs;                    // remainder (rare): from the LDS copy of the CSR arrays
   const double tfdeg_inv = la ? 1.0 / n.tf_deg[i] : 1.0;
   const double Ai = la ? par(sl.A + i) : 0.0, Bi = la ? par(sl.B + i) : 1.0, Ci = la ? par(sl.C + i) : 0.0, Di = own ? par(sl.D + i) : 1.0,
-               Ei = own ? par(sl.E + i) : 0.0, ts = par(sl.tf);
+               Ei = own ? par(sl.E + i) : 0.0, ts = uni(par(sl.tf));
   // rows of this lane: site index (or -1), loss coefficient E + Dp + D of a site row, validity
   int sj[NRL]; bool valid[NRL]; double Lk[NRL], Sr[NRL];
 #pragma unroll
@@ -75,7 +87,11 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
     valid[k] = site || (la && k < 2);
     Lk[k] = site ? Ei + par(sl.Dp + ss + j) + Di : 0.0;
     Sr[k] = 0.0;
+    if constexpr (PARK) { pst(P_LK + k, Lk[k]); pst(P_SR + k, 0.0); }
   }
+  // per-row constants and factors: registers, or (PARK) their LDS slots
+  auto LK = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_LK + k); else return Lk[k]; };
+  auto SR = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_SR + k); else return Sr[k]; };
   auto yoff = [&](int k) __attribute__((always_inline)) { return st + ((la && k < 2) ? k : 2 + sj[k]); };
   const double* y0 = A.y0 + (A.y0_batched ? b * S : 0);
   double* Yout = A.Y + b * (size_t)A.T * S;
@@ -90,7 +106,10 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
   write_row(0);
 
   // pair exchanges (executed by every lane, convergently): sum over the two lanes of a protein; lane A's value seen by both lanes
-  auto pair_sum = [&](double v) __attribute__((always_inline)) { const double o = dpp_mov<0xB1>(v); return paired ? v + o : v; };
+  // (masks as 0 / 1 factors instead of selects: one fma where a select costs two v_cndmask per double; a stray partner value is finite --
+  // every lane of the workgroup belongs to the same candidate, and a non-finite one fails the step's error test anyway)
+  const double mP = paired ? 1.0 : 0.0, mB = hb ? 1.0 : 0.0;
+  auto pair_sum = [&](double v) __attribute__((always_inline)) { return __builtin_fma(mP, dpp_mov<0xB1>(v), v); };
   auto from_a = [&](double v) __attribute__((always_inline)) { const double o = dpp_mov<0xA0>(v); return hb ? o : v; };
 
   double sumS = 0.0;
@@ -103,20 +122,27 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
     for (int k = 0; k < NRL; ++k) {
       double acc = 0.0;
       if (sj[k] >= 0) for (int q = n.W_indptr[ss + sj[k]]; q < n.W_indptr[ss + sj[k] + 1]; ++q) acc += n.W_data[q] * Kt[n.W_indices[q]];
-      Sr[k] = acc; acc_all += acc;
+      if constexpr (PARK) pst(P_SR + k, acc); else Sr[k] = acc;
+      acc_all += acc;
     }
     sumS = pair_sum(acc_all);
   };
 
   // frozen block Jacobian of the step (entries that depend on y_n) and the factors of g I - A
   double cRv = 0.0, gPv = 1.0, winvR = 1.0, sinv = 1.0, wv[NRL], cw[NRL];
+  auto WV = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_WV + k); else return wv[k]; };
+  auto CW = [&](int k) __attribute__((always_inline)) {                 // (S_k gP) w_k: kept (registers) or rebuilt from its parked factors
+    if constexpr (!PARK) return cw[k];
+    else if constexpr (MODEL == 4) return (pld(P_SR + k) * gPv) * pld(P_WV + k);
+    else return pld(P_SR + k) * pld(P_WV + k);
+  };
   int buf = 0;
   // f(Y) of the block -> f; with MATVEC also G = A Y (stage 1: Y = y_n).  One barrier.
   auto rhs_block = [&](const double (&Y)[NRL], double (&f)[NRL], double (&G)[NRL], auto mv) __attribute__((always_inline)) {
     constexpr bool MATVEC = decltype(mv)::value;
-    double part = 0.0;
+    double part = mB * Y[0];                            // rows 0, 1 are sites in the second lane only
 #pragma unroll
-    for (int k = 0; k < NRL; ++k) part += (k >= 2 || hb) ? Y[k] : 0.0;
+    for (int k = 1; k < NRL; ++k) part = (k >= 2) ? part + Y[k] : __builtin_fma(mB, Y[k], part);
     const double stot = pair_sum(part);                 // sum of the protein's phospho states
     const double Pb = from_a(Y[1]);                     // its protein state, in both lanes
     if (la) Pv[buf * N + i] = (drv >= 0) ? Kt[drv] : Y[1] + stot;
@@ -149,7 +175,7 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
     }
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {
-      const double fs = Sr[k] * q - Lk[k] * Y[k];
+      const double fs = SR(k) * q - LK(k) * Y[k];
       f[k] = (k == 0 && la) ? fR : (k == 1 && la) ? fP : fs;
     }
     if constexpr (MATVEC) {
@@ -157,7 +183,7 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
       const double gP_ = cRv * Y[0] - (Di + sumSg) * Y[1] + Ei * stot;
 #pragma unroll
       for (int k = 0; k < NRL; ++k) {
-        const double gs = (Sr[k] * gPv) * Pb - Lk[k] * Y[k];
+        const double gs = (SR(k) * gPv) * Pb - LK(k) * Y[k];
         G[k] = (k == 0 && la) ? -Bi * Y[0] : (k == 1 && la) ? gP_ : gs;
       }
     }
@@ -171,22 +197,26 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {                     // Sr = 0 on the mRNA / protein rows: they drop out of the sums by themselves
-      const double w = net_rcp(g + Lk[k]);
-      wv[k] = w; cw[k] = (Sr[k] * gPv) * w; part += Ei * cw[k];
+      const double w = net_rcp(g + LK(k)), c = (SR(k) * gPv) * w;
+      if constexpr (PARK) pst(P_WV + k, w); else { wv[k] = w; cw[k] = c; }
+      part += c;
     }
-    sinv = net_rcp(g + Di + sumS * gPv - pair_sum(part));
+    sinv = net_rcp(g + Di + sumS * gPv - Ei * pair_sum(part));
   };
   // x = (g I - A)^-1 r
   auto block_solve = [&](const double (&r)[NRL], double (&x)[NRL]) __attribute__((always_inline)) {
     const double xR = r[0] * winvR;
-    double t[NRL], part = 0.0;
+    double t[NRL];
 #pragma unroll
-    for (int k = 0; k < NRL; ++k) { t[k] = r[k] * wv[k]; part += (k >= 2 || hb) ? Ei * t[k] : 0.0; }
-    const double xP = (r[1] + cRv * xR + pair_sum(part)) * sinv;          // meaningful in lane A
+    for (int k = 0; k < NRL; ++k) t[k] = r[k] * WV(k);
+    double part = mB * t[0];
+#pragma unroll
+    for (int k = 1; k < NRL; ++k) part = (k >= 2) ? part + t[k] : __builtin_fma(mB, t[k], part);
+    const double xP = (r[1] + cRv * xR + Ei * pair_sum(part)) * sinv;     // meaningful in lane A
     const double xPb = from_a(xP);
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {
-      const double xs = __builtin_fma(cw[k], xPb, t[k]);
+      const double xs = __builtin_fma(CW(k), xPb, t[k]);
       x[k] = (k == 0 && la) ? xR : (k == 1 && la) ? xP : xs;
     }
   };
@@ -208,6 +238,7 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
     h = (d0 > 1e-5 && d1 > 1e-5) ? 0.01 * d0 / d1 : 1e-6;
     if (A.h0 > 0.0) h = A.h0;
     if (!(h > 0.0) || h != h) h = 1e-6;
+    h = uni(h);
   }
   const bool rms = A.err_rms;
   const double safety_inv = 1.0 / (A.ctl_safety > 0.0 ? A.ctl_safety : 0.9), grow_inv = 1.0 / (A.ctl_grow > 1.0 ? A.ctl_grow : 6.0);
@@ -217,11 +248,19 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
     while (true) {
       if (nacc + nrej >= A.max_steps) { status |= PK_ST_MAXSTEPS; break; }
       const bool last = (tc + 1.0001 * h >= te);
-      const double hs = last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h);
+      const double hs = uni(last ? te - tc : ((tc + 2.0 * h > te) ? 0.5 * (te - tc) : h));
       if (!(hs > 1e-14 * fmax(fabs(tc), 1e-3))) { status |= PK_ST_HMIN; break; }
-      const double g = net_rcp(hs * GAM);
+      const double g = uni(net_rcp(hs * GAM));
       freeze_factor(g);
       double Y[NRL], w[NRL], v[NRL], R[4][NRL], sb[NRL], se[NRL];
+      auto Rg = [&](auto ic, int k) __attribute__((always_inline)) {          // right-hand side R_{ii + 3}, row k
+        constexpr int ii = decltype(ic)::value;
+        if constexpr (PARK && ii >= 2) return pld((ii == 2 ? P_R5 : P_R6) + k); else return R[ii][k];
+      };
+      auto Rs = [&](auto ic, int k, double x) __attribute__((always_inline)) {
+        constexpr int ii = decltype(ic)::value;
+        if constexpr (PARK && ii >= 2) pst((ii == 2 ? P_R5 : P_R6) + k, x); else R[ii][k] = x;
+      };
       // ---- stage 1: Y_1 = y_n
       rhs_block(y, w, v, std::true_type{});
 #pragma unroll
@@ -232,7 +271,7 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
       static_for<4>([&](auto ic) {
         constexpr int ii = decltype(ic)::value;                              // R_{ii + 3}
 #pragma unroll
-        for (int k = 0; k < NRL; ++k) R[ii][k] = y[k] + AE[ii + 1][0] * w[k] + DI[ii + 1][0] * v[k];
+        for (int k = 0; k < NRL; ++k) Rs(ic, k, y[k] + AE[ii + 1][0] * w[k] + DI[ii + 1][0] * v[k]);
       });
       // ---- stages 2 .. 6
       static_for<5>([&](auto sc) {
@@ -241,7 +280,7 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
           double rk;
-          if constexpr (s == 2) rk = y[k] + AE[0][0] * w[k] + DI[0][0] * v[k]; else rk = R[s - 3][k];
+          if constexpr (s == 2) rk = y[k] + AE[0][0] * w[k] + DI[0][0] * v[k]; else rk = Rg(std::integral_constant<int, (s >= 3 ? s - 3 : 0)>{}, k);
           gr[k] = g * rk;
         }
         block_solve(gr, Y);
@@ -257,7 +296,7 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
           constexpr int ii = decltype(ic)::value;
           if constexpr (ii + 3 > s) {
 #pragma unroll
-            for (int k = 0; k < NRL; ++k) R[ii][k] = R[ii][k] + AE[ii + 1][s - 1] * w[k] + DI[ii + 1][s - 1] * v[k];
+            for (int k = 0; k < NRL; ++k) Rs(ic, k, Rg(ic, k) + AE[ii + 1][s - 1] * w[k] + DI[ii + 1][s - 1] * v[k]);
           }
         });
       });
@@ -269,23 +308,23 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
         sb[k] += y[k];                                                       // y_{n+1}
         if (valid[k]) e = err_acc(e, q(se[k], y[k], sb[k]), rms);
       }
-      const double err = err_reduce(e, rms, S, red);
+      const double err = uni(err_reduce(e, rms, S, red));
       if (err != err || err > 1e300) {
-        ++nrej; after_reject = true; h = 0.1 * hs;
+        ++nrej; after_reject = true; h = uni(0.1 * hs);
         double bad = (nonfinite(Ai) || nonfinite(Bi) || nonfinite(Ci) || nonfinite(Di) || nonfinite(Ei) || nonfinite(ts)) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < NRL; ++k) if (nonfinite(y[k]) || nonfinite(Lk[k]) || nonfinite(Sr[k])) bad = 1.0;
+        for (int k = 0; k < NRL; ++k) if (nonfinite(y[k]) || nonfinite(LK(k)) || nonfinite(SR(k))) bad = 1.0;
         if (block_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; break; }
         continue;
       }
       double fac = sqrt(sqrt(err)) * safety_inv;                             // embedded order 3: err^(1/4)
       fac = fmax(grow_inv, fmin(5.0, fac));
-      double hnew = hs * net_rcp(fac);
+      double hnew = uni(hs * net_rcp(fac));
       if (err <= 1.0) {
         ++nacc;
 #pragma unroll
         for (int k = 0; k < NRL; ++k) y[k] = sb[k];
-        tc += hs;
+        tc = uni(tc + hs);
         if (after_reject) hnew = fmin(hnew, hs);
         after_reject = false;
         if (last) { tc = te; h = (hs < h) ? fmax(hnew, h) : hnew; break; }
@@ -318,8 +357,17 @@ __global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, con
   }
 }
 
-__host__ inline size_t net_solve_arkp_lds_bytes(const NetDev& n, int nnzT) {
-  return ((size_t)n.n_K + 2 * (size_t)n.N + 24 + nnzT + (nnzT + 1) / 2) * 8;
+template <int MODEL, int NRL>
+__global__ __launch_bounds__(512) void net_solve_arkp_kernel(const NetDev n, const NetSolveArgs A) { net_solve_arkp_body<MODEL, NRL, false>(n, A); }
+
+// the register diet: 3 waves per SIMD (<= 168 VGPRs)
+template <int MODEL, int NRL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void net_solve_arkp3_kernel(const NetDev n, const NetSolveArgs A) {
+  net_solve_arkp_body<MODEL, NRL, true>(n, A);
+}
+
+__host__ inline size_t net_solve_arkp_lds_bytes(const NetDev& n, int rows_per_lane, int threads, bool park) {
+  return ((size_t)n.n_K + 2 * (size_t)n.N + 24 + (park ? (size_t)arkp_park_stride(rows_per_lane) * threads : 0)) * 8;
 }
 
 }  // namespace pk

@@ -306,6 +306,14 @@ def _fake_system(g, k):
                            TF_indices=g["TF_indices"], TF_data=g["TF_data"], tf_deg=g["tf_deg"], kin_grid=g["kin_grid"], kin_Kmat=g["kin_Kmat"],
                            c_k=g["c_k"][k].copy(), A_i=g["A_i"][k].copy(), B_i=g["B_i"][k].copy(), C_i=g["C_i"][k].copy(), D_i=g["D_i"][k].copy(),
                            Dp_i=g["Dp_i"][k].copy(), E_i=g["E_i"][k].copy(), tf_scale=float(g["tf_scale"][k]), y0=lambda: g["y0"].copy())
+
+    def update(**kw):                                # the contract of System.update (network.py:293-302): arrays in place, tf_scale a float
+        for name, val in kw.items():
+            if name == "tf_scale":
+                sysm.tf_scale = float(val)
+            else:
+                getattr(sysm, name)[:] = val
+    sysm.update = update
     return sysm, idx
 
 
