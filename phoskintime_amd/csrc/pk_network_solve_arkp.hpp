@@ -85,7 +85,9 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     const bool site = own && j >= 0 && j < ns;
     sj[k] = site ? j : -1;
     valid[k] = site || (la && k < 2);
-    Lk[k] = site ? Ei + par(sl.Dp + ss + j) + Di : 0.0;
+    // loss coefficient of the row's own state: E + Dp + D for a site; lane A's rows 0 / 1 (mRNA, protein) carry B and D, so the generic
+    // row formulas  f_k = S_k q - L_k Y_k,  x_k = r_k / (g + L_k) + ...  give the mRNA row outright and the diagonal part of the protein row
+    Lk[k] = site ? Ei + par(sl.Dp + ss + j) + Di : (la && k == 0) ? Bi : (la && k == 1) ? Di : 0.0;
     Sr[k] = 0.0;
     if constexpr (PARK) { pst(P_LK + k, Lk[k]); pst(P_SR + k, 0.0); }
   }
@@ -108,7 +110,7 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   // pair exchanges (executed by every lane, convergently): sum over the two lanes of a protein; lane A's value seen by both lanes
   // (masks as 0 / 1 factors instead of selects: one fma where a select costs two v_cndmask per double; a stray partner value is finite --
   // every lane of the workgroup belongs to the same candidate, and a non-finite one fails the step's error test anyway)
-  const double mP = paired ? 1.0 : 0.0, mB = hb ? 1.0 : 0.0;
+  const double mP = paired ? 1.0 : 0.0, mB = hb ? 1.0 : 0.0, mA = la ? 1.0 : 0.0;
   auto pair_sum = [&](double v) __attribute__((always_inline)) { return __builtin_fma(mP, dpp_mov<0xB1>(v), v); };
   auto from_a = [&](double v) __attribute__((always_inline)) { const double o = dpp_mov<0xA0>(v); return hb ? o : v; };
 
@@ -129,7 +131,7 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   };
 
   // frozen block Jacobian of the step (entries that depend on y_n) and the factors of g I - A
-  double cRv = 0.0, gPv = 1.0, winvR = 1.0, sinv = 1.0, wv[NRL], cw[NRL];
+  double cRv = 0.0, gPv = 1.0, sinv = 1.0, wv[NRL], cw[NRL];
   auto WV = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_WV + k); else return wv[k]; };
   auto CW = [&](int k) __attribute__((always_inline)) {                 // (S_k gP) w_k: kept (registers) or rebuilt from its parked factors
     if constexpr (!PARK) return cw[k];
@@ -165,26 +167,25 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     const bool pos = u >= 0.0;
     const double rden = net_rcp(pos ? 1.0 + u + 1e-6 : __builtin_fma(ts, fabs(u), 1.0));
     const double synth = pos ? Ai * __builtin_fma(ts * u, rden, 1.0) : Ai * rden;
-    const double fR = synth - Bi * Y[0];
-    double q = Pb, fP;
+    // lane A: row 0 = synth - B R (the generic row with S = 0, L = B, plus synth); row 1 = generic (-D P) + [C R - sumS q + E sum(sites)]
+    double q = Pb, eP;
     if (MODEL == 4) {
       q = Pb * net_rcp(1.0 + Pb);
-      fP = (Ci * Y[0]) * net_rcp(1.0 + Y[0]) - Di * Y[1] - sumS * q + Ei * stot;
+      eP = __builtin_fma(Ei, stot, __builtin_fma(-sumS, q, (Ci * Y[0]) * net_rcp(1.0 + Y[0])));
     } else {
-      fP = Ci * Y[0] - (Di + sumS) * Y[1] + Ei * stot;
+      eP = __builtin_fma(Ei, stot, __builtin_fma(-sumS, Y[1], Ci * Y[0]));
     }
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {
       const double fs = SR(k) * q - LK(k) * Y[k];
-      f[k] = (k == 0 && la) ? fR : (k == 1 && la) ? fP : fs;
+      f[k] = (k == 0) ? __builtin_fma(mA, synth, fs) : (k == 1) ? __builtin_fma(mA, eP, fs) : fs;
     }
     if constexpr (MATVEC) {
-      const double sumSg = sumS * gPv;
-      const double gP_ = cRv * Y[0] - (Di + sumSg) * Y[1] + Ei * stot;
+      const double gP_ = __builtin_fma(Ei, stot, __builtin_fma(-(sumS * gPv), Y[1], cRv * Y[0]));
 #pragma unroll
       for (int k = 0; k < NRL; ++k) {
         const double gs = (SR(k) * gPv) * Pb - LK(k) * Y[k];
-        G[k] = (k == 0 && la) ? -Bi * Y[0] : (k == 1 && la) ? gP_ : gs;
+        G[k] = (k == 1) ? __builtin_fma(mA, gP_, gs) : gs;
       }
     }
   };
@@ -193,11 +194,12 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     const double Pb = from_a(y[1]);
     gPv = sat ? net_rcp((1.0 + Pb) * (1.0 + Pb)) : 1.0;
     cRv = sat ? Ci * net_rcp((1.0 + y[0]) * (1.0 + y[0])) : Ci;
-    winvR = net_rcp(g + Bi);
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {                     // Sr = 0 on the mRNA / protein rows: they drop out of the sums by themselves
-      const double w = net_rcp(g + LK(k)), c = (SR(k) * gPv) * w;
+      double w = net_rcp(g + LK(k));                    // lane A, row 0: 1 / (g + B), the mRNA pivot
+      if (k == 1) w = la ? 0.0 : w;                     // lane A, row 1: the protein row is solved through the Schur pivot below, not here
+      const double c = (SR(k) * gPv) * w;
       if constexpr (PARK) pst(P_WV + k, w); else { wv[k] = w; cw[k] = c; }
       part += c;
     }
@@ -205,19 +207,18 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   };
   // x = (g I - A)^-1 r
   auto block_solve = [&](const double (&r)[NRL], double (&x)[NRL]) __attribute__((always_inline)) {
-    const double xR = r[0] * winvR;
     double t[NRL];
 #pragma unroll
     for (int k = 0; k < NRL; ++k) t[k] = r[k] * WV(k);
     double part = mB * t[0];
 #pragma unroll
     for (int k = 1; k < NRL; ++k) part = (k >= 2) ? part + t[k] : __builtin_fma(mB, t[k], part);
-    const double xP = (r[1] + cRv * xR + Ei * pair_sum(part)) * sinv;     // meaningful in lane A
+    const double xP = (r[1] + cRv * t[0] + Ei * pair_sum(part)) * sinv;   // meaningful in lane A (t[0] = the mRNA row's solution there)
     const double xPb = from_a(xP);
 #pragma unroll
     for (int k = 0; k < NRL; ++k) {
-      const double xs = __builtin_fma(CW(k), xPb, t[k]);
-      x[k] = (k == 0 && la) ? xR : (k == 1 && la) ? xP : xs;
+      const double xs = __builtin_fma(CW(k), xPb, t[k]);                  // lane A: rows 0 / 1 have CW = 0, row 1 also t = 0
+      x[k] = (k == 1) ? __builtin_fma(mA, xP, xs) : xs;
     }
   };
 
