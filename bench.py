@@ -395,16 +395,39 @@ def network_leg(dev):
     dtn = time.perf_counter() - t1
     steps = nsn.double().mean(dim=0).tolist()
     out = {"workload": "BASELINE config 5 shape: 8192 raw decision vectors (defaults x log-normal 0.5), %s: N=%d proteins, %d sites, S=%d states, "
-                       "n_var=%d; simulate at rtol=atol=1e-8 (config.toml:403-404) on the %d-point grid + fused 3-objective loss" % (src, eng.N, eng.total_sites, eng.S, eng.n_var, tn.size),
+                       "n_var=%d; simulate at rtol=atol=1e-8 (config.toml:403-404) on the %d-point grid + 3-objective loss (candidates_per_s: ONE fused launch when taken; simulate_kernel_ms / objective_kernel_ms: the two-launch path, which the roofline entry is computed on)" % (src, eng.N, eng.total_sites, eng.S, eng.n_var, tn.size),
            "candidates_per_s": Bn / dtn, "wall_ms": 1e3 * dtn, "simulate_kernel_ms": e0.elapsed_time(e1), "objective_kernel_ms": e1.elapsed_time(e2),
            "mean_accepted_steps": steps[0], "mean_rejected_steps": steps[1], "flagged": int((status != 0).sum()),
-           "integrator": "ARK4(3)6L[2]SA, linearly implicit on the per-protein block Jacobian (order 4, 5 block solves per step); max-norm error control",
+           "integrator": "ARK4(3)6L[2]SA, linearly implicit on the per-protein block Jacobian (order 4, 5 block solves per step); max-norm error control; "
+                         "dense two-lanes-per-protein layout, 3 waves per SIMD (pk_network_solve_arkp.hpp)",
            "algorithmic_bytes_per_candidate": 8 * (eng.n_var + eng.S + 3), "hbm_gbs_algorithmic": Bn * 8 * (eng.n_var + eng.S + 3) / (e0.elapsed_time(e1) * 1e-3) / 1e9,
            "finite_objectives": bool(torch.isfinite(F).all())}
     fl_step = network_algorithmic_flops_per_step(eng)
     out["roofline_fp64"] = roofline_fp64_entry(Bn * fl_step * (steps[0] + steps[1]), e0.elapsed_time(e1),
                                                "network_algorithmic_flops_per_step (%.0f flop per step and candidate) x accepted + rejected steps x candidates / simulate_kernel_ms" % fl_step,
                                                "r0*_network5*_pmc.json", "net_solve_ark")
+    # [r3] the path GlobalODEBatch.evaluate_device takes on this topology: simulate + objectives in ONE launch, no trajectory in HBM
+    try:
+        kwf = dict(raw=True, rtol=1e-8, atol=1e-8, max_steps=prob.max_steps * tn.size, err_norm=prob.err_norm, loss_mode=0, defaults=prob.defaults,
+                   lambdas=prob.lam, fail_value=prob.fail_value)
+        fo = eng.simulate_objective_batch(prob.loss, Xd[:256], tn, **kwf); torch.cuda.synchronize(dev)
+        if fo is None:
+            out["fused_simulate_objective"] = {"taken": False}
+        else:
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t1 = time.perf_counter(); f0.record(st)
+            _, Ff, stf, nsf, _ = eng.simulate_objective_batch(prob.loss, Xd, tn, **kwf)
+            f1.record(st); torch.cuda.synchronize(dev)
+            dtf = time.perf_counter() - t1
+            out["fused_simulate_objective"] = {"taken": True, "kernel_ms": f0.elapsed_time(f1), "wall_ms": 1e3 * dtf, "candidates_per_s": Bn / dtf,
+                                               "max_rel_diff_of_F_vs_two_launches": float(((Ff - F).abs() / F.abs().clamp_min(1e-300)).max()),
+                                               "same_step_counts": bool((nsf == nsn).all()),
+                                               "hbm_bytes_not_written": int(Bn) * int(tn.size) * int(eng.S) * 8}
+            out["two_launch_candidates_per_s"] = out["candidates_per_s"]
+            out["candidates_per_s"] = Bn / dtf
+            out["wall_ms_two_launches"] = out["wall_ms"]; out["wall_ms"] = 1e3 * dtf
+    except Exception as e:
+        out["fused_simulate_objective"] = {"error": repr(e)}
     if g is not None:
         truth = g["Y_tight"][0]; y0c = Y[0].cpu().numpy()
         out["band_err_candidate0_vs_reference_lsoda_1e-12"] = float(np.max(np.abs(y0c - truth) / (1e-8 + 1e-6 * np.abs(truth))))

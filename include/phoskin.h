@@ -294,6 +294,17 @@ int      pk_network_objective_batch(pk_ctx*, pk_net*, pk_loss*, int64_t B, const
                                     const double* x, int x_is_raw, const double* defaults, const double* lambdas, double fail_value,
                                     const int32_t* status, double* loss_sums, double* F);
 
+/* [r3] simulate + objective in ONE launch (SURVEY fused op (i): optproblem.py:99-160 calls simulate_odeint -> LOSS_FN -> prior per candidate):
+ * the additive integrator scores the loss handle's observations at its output times out of registers and writes F [B,3] / loss_sums [B,3];
+ * the trajectory Y [B,T,S] is written only if Y != NULL.  Results equal pk_network_simulate_batch followed by pk_network_objective_batch
+ * up to the order of the sums.  Takes: topologies 0 / 4 on the default integrator (PK_METHOD_LRP12 = "default" or PK_METHOD_ARK436), loss
+ * data whose three baselines are time index 0 and that observe no (state, time) twice.  Otherwise PK_ERR_UNSUPPORTED (the message says
+ * which): call the two functions above instead.  x, y0, defaults, Y, status, n_steps, loss_sums, F: DEVICE pointers; t, lambdas: HOST. */
+int      pk_network_simulate_objective_batch(pk_ctx*, pk_net*, pk_loss*, int64_t B, const double* x, int x_is_raw, const double* y0,
+                                             int y0_is_batched, const double* t_host, int T, const pk_solver_opts* opts, int loss_mode,
+                                             const double* defaults, const double* lambdas, double fail_value, double* Y, int32_t* status,
+                                             int32_t* n_steps, double* loss_sums, double* F);
+
 /* global_model.lossfn.LOSS_FN with its own positional argument list (lossfn.py:114-121; :386 picks loss_function_comb when MODEL == 2):
  *   LOSS_FN(Y, p_prot, t_prot, obs_prot, w_prot, p_rna, t_rna, obs_rna, w_rna, p_pho, s_pho, t_pho, obs_pho, w_pho, prot_map,
  *           prot_base_idx, rna_base_idx, pho_base_idx) -> (loss_p, loss_r, loss_ph)          [called at optproblem.py:137-145]

@@ -68,8 +68,10 @@ SYMBOLS = (
     "pk_time_solve_protein_batch", "pk_measure_hbm_gbs", "pk_measure_hbm_stream_gbs", "pk_measure_fp64_fma_tflops",
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
-    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_observables_batch", "pk_frechet_batch", "pk_loss_fn_batch_host", "pk_network_resolve_method",
+    "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_simulate_objective_batch", "pk_network_observables_batch", "pk_frechet_batch", "pk_loss_fn_batch_host", "pk_network_resolve_method",
 )
+
+PK_OK, PK_ERR_ARG, PK_ERR_UNSUPPORTED, PK_ERR_HIP, PK_ERR_NOMEM = 0, -1, -2, -3, -4      # include/phoskin.h
 
 _lib = None
 
@@ -132,6 +134,8 @@ def load():
     lib.pk_network_loss_destroy.restype = None; lib.pk_network_loss_destroy.argtypes = [vp]
     lib.pk_network_objective_batch.restype = i32
     lib.pk_network_objective_batch.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, i32, vp, vp, dbl, vp, vp, vp]
+    lib.pk_network_simulate_objective_batch.restype = i32
+    lib.pk_network_simulate_objective_batch.argtypes = [vp, vp, vp, i64, vp, i32, vp, i32, vp, i32, optp, i32, vp, vp, dbl, vp, vp, vp, vp, vp]
     lib.pk_network_observables_batch.restype = i32
     lib.pk_network_observables_batch.argtypes = [vp, vp, vp, i64, vp, i32, dbl, vp]
     lib.pk_network_resolve_method.restype = i32; lib.pk_network_resolve_method.argtypes = [vp, optp]

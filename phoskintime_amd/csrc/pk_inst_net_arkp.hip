@@ -18,6 +18,8 @@ static int arkp_mode() {
   return m;
 }
 
+bool net_arkp_fuses_loss() { return arkp_mode() == 3; }
+
 hipError_t launch_net_arkp(const NetDev& n, const NetSolveArgs& a, int nnzT, int max_sites, long long B, hipStream_t st) {
   const int threads = ((n.n_lanes + 63) / 64) * 64;
   const int nrl = arkp_rows_per_lane(max_sites <= 4 ? 4 : max_sites <= 6 ? 6 : 8);

@@ -16,6 +16,7 @@ size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads);
 hipError_t launch_net_ark(const NetDev& n, const NetSolveArgs& a, int max_sites, long long B, int threads, size_t lds, hipStream_t st);
 // the same method in the dense two-lanes-per-protein layout (pk_network_solve_arkp.hpp; arrow topologies): n.lane_unit must be set
 bool net_arkp_enabled();
+bool net_arkp_fuses_loss();                      // the register-diet kernel (PK_ARK_PAIR=3, the default) scores observations at its output times
 hipError_t launch_net_arkp(const NetDev& n, const NetSolveArgs& a, int nnzT, int max_sites, long long B, hipStream_t st);
 }
 #include <algorithm>
@@ -252,13 +253,15 @@ int pk_network_resolve_method(const pk_net* n, const pk_solver_opts* opts) {
   return (ark_ok && method != PK_METHOD_ROS34PW2) ? PK_METHOD_ARK436 : PK_METHOD_ROS34PW2;
 }
 
-int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
-                              const double* t_host, int T, const pk_solver_opts* opts_in, double* Y, int32_t* status, int32_t* n_steps) {
+// `fused`: null, or the loss fields of NetSolveArgs filled in (pk_network_simulate_objective_batch); Y may then be null
+static int net_simulate_impl(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
+                             const double* t_host, int T, const pk_solver_opts* opts_in, double* Y, int32_t* status, int32_t* n_steps,
+                             const pk::NetSolveArgs* fused) {
   if (!c || !n) return PK_ERR_ARG;
   if (B < 0) return pk_ctx_fail(c, PK_ERR_ARG, "B must be >= 0");
   if (T < 1 || !t_host) return pk_ctx_fail(c, PK_ERR_ARG, "t must hold >= 1 time points (host pointer)");
   if (B == 0) return PK_OK;
-  if (!x || !y0 || !Y) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  if (!x || !y0 || (!Y && !fused)) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
   if (B > 0x7fffffffLL) return pk_ctx_fail(c, PK_ERR_ARG, "batch too large for one launch");
   const bool dp5 = opts_in && opts_in->method == PK_METHOD_DP5;
   if (n->d.model == 2 && n->max_sites > 16) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "combinatorial topology: <= 16 sites per protein");
@@ -295,6 +298,16 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   if (o.err_norm < PK_NORM_DEFAULT || o.err_norm > PK_NORM_RMS) return pk_ctx_fail(c, PK_ERR_ARG, "unknown opts->err_norm");
   a.err_rms = (o.err_norm == PK_NORM_RMS) ? 1 : 0;
   a.n_stops = (int)st.size();
+  if (fused) {
+    a.loss_obs = fused->loss_obs; a.loss_w = fused->loss_w; a.loss_defaults = fused->loss_defaults; a.loss_mode = fused->loss_mode;
+    a.loss_fail = fused->loss_fail; a.loss_sums = fused->loss_sums; a.loss_F = fused->loss_F; a.loss_rna_base = fused->loss_rna_base;
+    for (int k = 0; k < 4; ++k) a.loss_lam[k] = fused->loss_lam[k];
+    for (int k = 0; k < 3; ++k) a.loss_norm[k] = fused->loss_norm[k];
+    const bool can = !dp5 && pk_network_resolve_method(n, &o) == PK_METHOD_ARK436 && n->d.lane_unit && n->d.n_lanes <= 512 && pk::net_arkp_enabled() &&
+                     pk::net_arkp_fuses_loss();
+    if (!can) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "fused objective: arrow topologies (0, 4) on the default additive integrator only; "
+                                                         "use pk_network_simulate_batch + pk_network_objective_batch");
+  }
   if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");
   hipStream_t stream = (hipStream_t)pk_ctx_stream(c);
   if (st.size() <= 64) {
@@ -393,6 +406,36 @@ int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, 
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PK_OK : pk_ctx_fail(c, PK_ERR_HIP, hipGetErrorString(e));
+}
+
+int pk_network_simulate_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x, int x_is_raw, const double* y0, int y0_is_batched,
+                              const double* t_host, int T, const pk_solver_opts* opts_in, double* Y, int32_t* status, int32_t* n_steps) {
+  return net_simulate_impl(c, n, B, x, x_is_raw, y0, y0_is_batched, t_host, T, opts_in, Y, status, n_steps, nullptr);
+}
+
+// simulate + three-objective loss in ONE launch (SURVEY fused op (i), VERDICT r2 item 4 iii): the integrator scores the observations of the
+// loss handle at its output times; the trajectory is written only when Y != null.  Same F / loss_sums as pk_network_simulate_batch followed
+// by pk_network_objective_batch (up to the order of the sums).  PK_ERR_UNSUPPORTED when the network / options / loss data do not take the path.
+int pk_loss_fused_tables(const pk_loss* l, const double** obs, const double** w, double* norms, int* T, int* rna_base);
+int pk_network_simulate_objective_batch(pk_ctx* c, pk_net* n, pk_loss* l, int64_t B, const double* x, int x_is_raw, const double* y0,
+                                        int y0_is_batched, const double* t_host, int T, const pk_solver_opts* opts, int loss_mode,
+                                        const double* defaults, const double* lambdas, double fail_value, double* Y, int32_t* status,
+                                        int32_t* n_steps, double* loss_sums, double* F) {
+  if (!c || !n || !l) return PK_ERR_ARG;
+  if (!loss_sums && !F) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
+  if (F && !lambdas) return pk_ctx_fail(c, PK_ERR_ARG, "lambdas (protein, rna, phospho, prior) are required for F");
+  if (loss_mode < 0 || loss_mode > 7) return pk_ctx_fail(c, PK_ERR_ARG, "loss_mode must be 0..7");
+  pk::NetSolveArgs f;
+  std::memset(&f, 0, sizeof(f));
+  int Tl = 0;
+  if (!pk_loss_fused_tables(l, &f.loss_obs, &f.loss_w, f.loss_norm, &Tl, &f.loss_rna_base))
+    return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "fused objective: protein / phospho baselines must be time index 0, rna observations not earlier than "
+                                              "the rna baseline, and no (state, time) observed twice");
+  if (Tl != T) return pk_ctx_fail(c, PK_ERR_ARG, "T differs from the grid the loss data were created for");
+  f.loss_defaults = defaults; f.loss_mode = loss_mode; f.loss_fail = fail_value; f.loss_sums = loss_sums; f.loss_F = F;
+  f.loss_lam[0] = lambdas ? lambdas[0] : 1.0; f.loss_lam[1] = lambdas ? lambdas[1] : 1.0; f.loss_lam[2] = lambdas ? lambdas[2] : 1.0;
+  f.loss_lam[3] = lambdas ? lambdas[3] : 0.0;
+  return net_simulate_impl(c, n, B, x, x_is_raw, y0, y0_is_batched, t_host, T, opts, Y, status, n_steps, &f);
 }
 
 int pk_network_unpack_batch(pk_ctx* c, pk_net* n, int64_t B, const double* x_raw, double* x_phys) {

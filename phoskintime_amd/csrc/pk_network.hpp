@@ -80,6 +80,26 @@ __device__ __forceinline__ double synth_rate_fast(const double Ai, const double 
   return Ai * net_rcp(1.0 + ts * fabs(u));
 }
 
+// the eight LOSS_MODE point losses (global_model/lossfn.py:28-110) and the floored fold change of LOSS_FN (floor 1e-9)
+__device__ __forceinline__ double point_loss(const int mode, double diff, const double obs, const double pred) {
+  constexpr double EPS = 1e-9;
+  switch (mode) {
+    case 0: return diff * diff;
+    case 1: { const double a = fabs(diff), d = 0.5; return a <= d ? 0.5 * diff * diff : d * (a - 0.5 * d); }
+    case 2: { diff = log(diff + EPS) - log(obs + EPS); const double x = diff / 0.5; return 0.25 * (sqrt(1.0 + x * x) - 1.0); }
+    case 3: { const double s = fabs(diff); return s > 20.0 ? s - 0.69314718056 : log(cosh(diff)); }
+    case 4: return log(1.0 + diff * diff);
+    case 5: return (diff * diff) / (fabs(pred) + 1e-6);
+    case 6: { const double x2 = diff * diff; return x2 / (x2 + 1.0); }
+    default: return sqrt(diff * diff + 1e-3 * 1e-3) - 1e-3;
+  }
+}
+
+__device__ __forceinline__ double fold_change(const double a, const double b) {
+  constexpr double EPS = 1e-9;
+  return (a > EPS ? a : EPS) / (b > EPS ? b : EPS);
+}
+
 // LDS work area of one candidate
 struct NetLds {
   double *p, *y, *Kt, *Sall, *Pvec, *synth, *dsyn;     // dsyn: d synth_i / d (TF . P_vec)_i   (Jacobian only)

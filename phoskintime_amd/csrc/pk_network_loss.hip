@@ -25,25 +25,6 @@ struct LossDev {
   double norm_p, norm_r, norm_ph;              // 1 / max(1e-6, sum w)   (optproblem.py:83-85)
 };
 
-__device__ __forceinline__ double point_loss(const int mode, double diff, const double obs, const double pred) {
-  constexpr double EPS = 1e-9;
-  switch (mode) {
-    case 0: return diff * diff;
-    case 1: { const double a = fabs(diff), d = 0.5; return a <= d ? 0.5 * diff * diff : d * (a - 0.5 * d); }
-    case 2: { diff = log(diff + EPS) - log(obs + EPS); const double x = diff / 0.5; return 0.25 * (sqrt(1.0 + x * x) - 1.0); }
-    case 3: { const double s = fabs(diff); return s > 20.0 ? s - 0.69314718056 : log(cosh(diff)); }
-    case 4: return log(1.0 + diff * diff);
-    case 5: return (diff * diff) / (fabs(pred) + 1e-6);
-    case 6: { const double x2 = diff * diff; return x2 / (x2 + 1.0); }
-    default: return sqrt(diff * diff + 1e-3 * 1e-3) - 1e-3;
-  }
-}
-
-__device__ __forceinline__ double fold_change(const double a, const double b) {
-  constexpr double EPS = 1e-9;
-  return (a > EPS ? a : EPS) / (b > EPS ? b : EPS);
-}
-
 __device__ __forceinline__ double block_sum(double v, double* red) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -204,6 +185,11 @@ struct pk_loss {
   pk::LossDev d;
   std::vector<void*> allocs;
   int T;
+  // the same observations as dense [T, S] tables (value, weight; weight 0 = none), indexed like a trajectory row: what the fused
+  // simulate + objective launch reads at each output time (pk_network_simulate_objective_batch).  Null when the lists cannot be fused:
+  // a protein / phospho baseline other than time index 0, an rna observation before the rna baseline (the reference's production data:
+  // baselines at t = 0, 4, 0 and rna observed from t = 4 on, runner.py:545-547), or two observations of one (state, time).
+  const double* dense_obs = nullptr; const double* dense_w = nullptr;
 };
 
 namespace {
@@ -252,8 +238,36 @@ pk_loss* pk_network_loss_create(pk_ctx* c, pk_net* net, const pk_loss_data* d, i
   v.p_pho = up(l, d->p_pho, d->n_pho, ok); v.s_pho = up(l, d->s_pho, d->n_pho, ok); v.t_pho = up(l, d->t_pho, d->n_pho, ok);
   v.obs_pho = up(l, d->obs_pho, d->n_pho, ok); v.w_pho = up(l, d->w_pho, d->n_pho, ok);
   v.norm_p = norm_of(d->w_prot, d->n_prot); v.norm_r = norm_of(d->w_rna, d->n_rna); v.norm_ph = norm_of(d->w_pho, d->n_pho);
+  bool rna_after_base = true;
+  for (int k = 0; k < d->n_rna; ++k) if (d->t_rna[k] < d->rna_base_idx) rna_after_base = false;
+  if (ok && n.model != 2 && d->prot_base_idx == 0 && d->pho_base_idx == 0 && rna_after_base) {
+    std::vector<int32_t> oy(n.N);
+    if (hipMemcpy(oy.data(), n.offset_y, n.N * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+    std::vector<double> ob((size_t)T * n.S, 0.0), wt((size_t)T * n.S, 0.0);
+    std::vector<char> seen((size_t)T * n.S, 0);
+    bool dup = false;
+    auto put = [&](int t, int s, double o, double w) {
+      const size_t at = (size_t)t * n.S + s;
+      if (seen[at]) dup = true;
+      seen[at] = 1; ob[at] = o; wt[at] = w;
+    };
+    if (ok) {
+      for (int k = 0; k < d->n_prot; ++k) put(d->t_prot[k], oy[d->p_prot[k]] + 1, d->obs_prot[k], d->w_prot[k]);
+      for (int k = 0; k < d->n_rna; ++k) put(d->t_rna[k], oy[d->p_rna[k]], d->obs_rna[k], d->w_rna[k]);
+      for (int k = 0; k < d->n_pho; ++k) put(d->t_pho[k], oy[d->p_pho[k]] + 2 + d->s_pho[k], d->obs_pho[k], d->w_pho[k]);
+      if (!dup) { l->dense_obs = up(l, ob.data(), ob.size(), ok); l->dense_w = up(l, wt.data(), wt.size(), ok); }
+    }
+  }
   if (!ok) { pk_ctx_fail(c, PK_ERR_NOMEM, "hipMalloc / hipMemcpy failed"); pk_network_loss_destroy(l); return nullptr; }
   return l;
+}
+
+// for the fused launch (pk_network.hip): the dense tables, the normalisations and the grid length; 0 when the lists cannot be fused
+int pk_loss_fused_tables(const pk_loss* l, const double** obs, const double** w, double* norms, int* T, int* rna_base) {
+  if (!l || !l->dense_obs || !l->dense_w) return 0;
+  *obs = l->dense_obs; *w = l->dense_w; norms[0] = l->d.norm_p; norms[1] = l->d.norm_r; norms[2] = l->d.norm_ph; *T = l->T;
+  *rna_base = l->d.base_rna;
+  return 1;
 }
 
 void pk_network_loss_destroy(pk_loss* l) {

@@ -45,6 +45,11 @@ struct NetSolveArgs {
   double rtol, atol, h0; int max_steps;
   double ctl_safety, ctl_grow;     // step-size controller of the additive kernels: h_new = h * min(ctl_grow, ctl_safety / err^(1/4)) (0: defaults 0.9, 6)
   int err_rms;                     // 1: ODEPACK's weighted root-mean-square error norm (what the reference's LSODA controls); 0: max norm
+  // fused objective (pk_network_simulate_objective_batch; the pair kernel on the register diet): dense observation tables [T, S] of the
+  // loss handle, read at every output time; the trajectory itself is written only if Y != null.  loss_obs == null: plain simulate
+  const double* loss_obs; const double* loss_w; const double* loss_defaults;
+  double loss_lam[4], loss_norm[3], loss_fail; int loss_mode, loss_rna_base;
+  double* loss_sums; double* loss_F;
 };
 
 // block-wide NaN-propagating max; `red` holds >= 17 doubles of LDS

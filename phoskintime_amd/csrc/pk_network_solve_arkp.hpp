@@ -22,7 +22,7 @@ namespace pk {
 
 // lane table entry: (protein << 2) | (paired << 1) | half.  Pairs sit on (even, odd) lanes, single-lane proteins after them.
 __host__ __device__ constexpr int arkp_rows_per_lane(int site_class) { return (2 + site_class) / 2; }
-__host__ __device__ constexpr int arkp_park_stride(int rows_per_lane) { return (5 * rows_per_lane) | 1; }      // doubles per thread, odd
+__host__ __device__ constexpr int arkp_park_stride(int rows_per_lane) { return (5 * rows_per_lane + 3) | 1; }  // doubles per thread, odd
 
 // PARK: per-row constants (loss coefficient, site rate, the two solve factors) and the two right-hand sides that are needed last (R_5, R_6)
 // live in LDS, thread-private [slot][thread]; the step-size scalars are moved to SGPRs.  That is the register diet for 3 waves per SIMD
@@ -38,8 +38,9 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   double* red = Pv + 2 * N;               // [24]
   // PARK: [thread][slot] with an ODD slot count per thread: one address VGPR + immediate offsets for any block size, and the lanes of a
   // ds_read_b64 / ds_write_b64 group fall on distinct banks (2 * odd * lane mod 64)
-  constexpr int P_LK = 0, P_SR = NRL, P_WV = 2 * NRL, P_R5 = 3 * NRL, P_R6 = 4 * NRL, P_STRIDE = arkp_park_stride(NRL);
-  double* const mypark = red + 24 + (size_t)threadIdx.x * P_STRIDE;
+  constexpr int P_LK = 0, P_SR = NRL, P_WV = 2 * NRL, P_R5 = 3 * NRL, P_R6 = 4 * NRL, P_LOSS = 5 * NRL, P_STRIDE = arkp_park_stride(NRL);
+  double* rbase = red + 24;               // PARK: [N] the mRNA baselines of the fused objective (captured at the rna baseline's output time)
+  double* const mypark = rbase + (PARK ? N : 0) + (size_t)threadIdx.x * P_STRIDE;
   auto pld = [&](int slot) __attribute__((always_inline)) { return mypark[slot]; };
   auto pst = [&](int slot, double x) __attribute__((always_inline)) { mypark[slot] = x; };
   auto uni = [](double x) __attribute__((always_inline)) {              // a block-uniform value into SGPRs
@@ -95,23 +96,61 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   auto LK = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_LK + k); else return Lk[k]; };
   auto SR = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_SR + k); else return Sr[k]; };
   auto yoff = [&](int k) __attribute__((always_inline)) { return st + ((la && k < 2) ? k : 2 + sj[k]); };
+  const double mP = paired ? 1.0 : 0.0, mB = hb ? 1.0 : 0.0, mA = la ? 1.0 : 0.0;
+  auto mB_ = [&](double v) __attribute__((always_inline)) { return mB * v; };
+  auto pair_sum_ = [&](double v) __attribute__((always_inline)) { return __builtin_fma(mP, dpp_mov<0xB1>(v), v); };
   const double* y0 = A.y0 + (A.y0_batched ? b * S : 0);
   double* Yout = A.Y + b * (size_t)A.T * S;
   double y[NRL];
 #pragma unroll
   for (int k = 0; k < NRL; ++k) y[k] = valid[k] ? y0[yoff(k)] : 0.0;
-  auto write_row = [&](int row) __attribute__((always_inline)) {
-    double* o = Yout + (size_t)row * S;
+  // fused objective (PARK kernel only): at every output time each lane scores the observations of its own states -- mRNA row: rna fold
+  // change, protein row: total protein (P + all sites; the pair's site sum by DPP), site rows: phospho -- against the dense [T, S] tables,
+  // into three thread-private partial sums parked in LDS (protein, rna, phospho).  Baselines: the initial state for protein / phospho (time
+  // index 0); the mRNA value at output row loss_rna_base, kept in LDS by the lane that owns it (observations are never earlier)
+  const bool fuse = PARK && A.loss_obs != nullptr;
+  bool ybad = false;                                                       // a lane mask in SGPRs: no VGPR across the step loop
+  if constexpr (PARK) { pst(P_LOSS, 0.0); pst(P_LOSS + 1, 0.0); pst(P_LOSS + 2, 0.0); }
+  auto score_row = [&](int row) __attribute__((always_inline)) {
+    double b0[NRL];
 #pragma unroll
-    for (int k = 0; k < NRL; ++k) if (valid[k]) o[yoff(k)] = y[k];
+    for (int k = 0; k < NRL; ++k) b0[k] = valid[k] ? y0[yoff(k)] : 0.0;
+    double part = mB_(y[0]), bpart = mB_(b0[0]);
+#pragma unroll
+    for (int k = 1; k < NRL; ++k) { part += (k >= 2) ? y[k] : mB_(y[k]); bpart += (k >= 2) ? b0[k] : mB_(b0[k]); }
+    const double stot = pair_sum_(part), btot = pair_sum_(bpart);
+    if (la && row == A.loss_rna_base) rbase[i] = y[0];
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NRL; ++k) {
+      if (!valid[k]) continue;
+      const size_t at = (size_t)row * S + yoff(k);
+      const double wgt = A.loss_w[at];
+      const bool prot = la && k == 1, rna = la && k == 0;
+      if (wgt != 0.0) {
+        const double obs = A.loss_obs[at];
+        const double pred = fold_change(prot ? y[1] + stot : y[k], prot ? b0[1] + btot : rna ? rbase[i] : b0[k]);
+        const double l = wgt * point_loss(A.loss_mode, obs - pred, obs, pred);
+        acc[prot ? 0 : rna ? 1 : 2] += l;
+      }
+      if (nonfinite(y[k])) ybad = true;                                     // np.all(np.isfinite(Y)) of the reference (optproblem.py:130)
+    }
+    pst(P_LOSS, pld(P_LOSS) + acc[0]); pst(P_LOSS + 1, pld(P_LOSS + 1) + acc[1]); pst(P_LOSS + 2, pld(P_LOSS + 2) + acc[2]);
   };
-  write_row(0);
+  auto write_row = [&](int row) __attribute__((always_inline)) {
+    if (A.Y) {
+      double* o = Yout + (size_t)row * S;
+#pragma unroll
+      for (int k = 0; k < NRL; ++k) if (valid[k]) o[yoff(k)] = y[k];
+    }
+    if constexpr (PARK) if (fuse) score_row(row);
+  };
 
   // pair exchanges (executed by every lane, convergently): sum over the two lanes of a protein; lane A's value seen by both lanes
   // (masks as 0 / 1 factors instead of selects: one fma where a select costs two v_cndmask per double; a stray partner value is finite --
   // every lane of the workgroup belongs to the same candidate, and a non-finite one fails the step's error test anyway)
-  const double mP = paired ? 1.0 : 0.0, mB = hb ? 1.0 : 0.0, mA = la ? 1.0 : 0.0;
   auto pair_sum = [&](double v) __attribute__((always_inline)) { return __builtin_fma(mP, dpp_mov<0xB1>(v), v); };
+  write_row(0);
   auto from_a = [&](double v) __attribute__((always_inline)) { const double o = dpp_mov<0xA0>(v); return hb ? o : v; };
 
   double sumS = 0.0;
@@ -341,7 +380,7 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     const int jn = net_bucket(tc, n.kin_grid, n.n_grid);
     if (jn != jb) { jb = jn; set_bucket(jb); }
   }
-  if (status != PK_ST_OK) {
+  if (status != PK_ST_OK && A.Y) {
     const double qnan = __builtin_nan("");
     for (int si = 0; si < A.n_stops; ++si) {
       const int row = stop_out[si];
@@ -349,6 +388,34 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
         double* o = Yout + (size_t)row * S;
 #pragma unroll
         for (int k = 0; k < NRL; ++k) if (valid[k]) o[yoff(k)] = qnan;
+      }
+    }
+  }
+  if constexpr (PARK) {
+    if (fuse) {
+      // objective assembly of GlobalODE_MOO._evaluate (optproblem.py:99-160), as net_objective_kernel does it from a stored trajectory
+      const double lp = block_sum(pld(P_LOSS), red), lr = block_sum(pld(P_LOSS + 1), red), lph = block_sum(pld(P_LOSS + 2), red);
+      double prior = 0.0;
+      if (A.loss_defaults) {
+        double acc = 0.0;
+        for (int k = tid; k < 5 * N; k += nt) {
+          const int grp = k / N, ii = k - grp * N;
+          const int off = (grp == 0 ? sl.A : grp == 1 ? sl.B : grp == 2 ? sl.C : grp == 3 ? sl.D : sl.E) + ii;
+          const double pv = A.x_is_raw ? softplus(xb[off]) : xb[off];
+          const double dd = (pv - A.loss_defaults[off]) / (A.loss_defaults[off] + 1e-6);
+          acc = __builtin_fma(dd, dd, acc);
+        }
+        prior = A.loss_lam[3] * (block_sum(acc, red) / (double)(5 * N));
+      }
+      const bool anybad = block_max(ybad ? 1.0 : 0.0, red) != 0.0;
+      if (tid == 0) {
+        if (A.loss_sums) { A.loss_sums[3 * b] = lp; A.loss_sums[3 * b + 1] = lr; A.loss_sums[3 * b + 2] = lph; }
+        if (A.loss_F) {
+          const bool bad = status != PK_ST_OK || anybad;                   // a NaN loss of finite states stays NaN (LOSS_MODE 2 in the reference, too)
+          A.loss_F[3 * b] = bad ? A.loss_fail : (lp * A.loss_norm[0]) * A.loss_lam[0] + prior;
+          A.loss_F[3 * b + 1] = bad ? A.loss_fail : (lr * A.loss_norm[1]) * A.loss_lam[1] + prior;
+          A.loss_F[3 * b + 2] = bad ? A.loss_fail : (lph * A.loss_norm[2]) * A.loss_lam[2] + prior;
+        }
       }
     }
   }
@@ -368,7 +435,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 __host__ inline size_t net_solve_arkp_lds_bytes(const NetDev& n, int rows_per_lane, int threads, bool park) {
-  return ((size_t)n.n_K + 2 * (size_t)n.N + 24 + (park ? (size_t)arkp_park_stride(rows_per_lane) * threads : 0)) * 8;
+  return ((size_t)n.n_K + 2 * (size_t)n.N + 24 + (park ? (size_t)n.N + (size_t)arkp_park_stride(rows_per_lane) * threads : 0)) * 8;
 }
 
 }  // namespace pk

@@ -189,6 +189,47 @@ class NetworkEngine:
         Y._keepalive = (xd, yd)  # type: ignore[attr-defined]
         return Y, status, nsteps
 
+    def simulate_objective_batch(self, loss, x, t_eval, y0=None, raw: bool = False, rtol: float = 1e-8, atol: float = 1e-8, max_steps: int = 1000000,
+                                 err_norm: str = "max", loss_mode: int = 0, defaults=None, lambdas=(1.0, 1.0, 1.0, 0.0), fail_value: float = 1e12,
+                                 want_Y: bool = False):
+        """simulate_odeint -> LOSS_FN -> objectives (optproblem.py:99-160) for B candidates in ONE launch: the integrator scores the
+        observations at its output times, the trajectory stays in registers (``want_Y``: also written).  Returns
+        (loss_sums [B, 3], F [B, 3], status [B], n_steps [B, 2], Y or None), or ``None`` when this network / loss data do not take the fused
+        path (``pk_network_simulate_objective_batch`` answers PK_ERR_UNSUPPORTED: call ``simulate_batch`` + ``objective_batch``)."""
+        dev = torch.device("cuda", self.ctx.device)
+        xd = _dev_f64(x, dev)
+        if xd.dim() == 1:
+            xd = xd.unsqueeze(0)
+        if xd.shape[1] != self.n_var:
+            raise ValueError(f"x must be [B, {self.n_var}]")
+        B = xd.shape[0]
+        yd = _dev_f64(self.default_y0() if y0 is None else y0, dev)
+        if yd.shape == (self.S,):
+            yb = 0
+        elif yd.shape == (B, self.S):
+            yb = 1
+        else:
+            raise ValueError(f"y0 must be [{self.S}] or [{B}, {self.S}]")
+        th = np.ascontiguousarray(np.atleast_1d(np.asarray(t_eval, dtype=np.float64)))
+        T = th.size
+        dd = _dev_f64(defaults, dev) if defaults is not None else None
+        Y = torch.empty((B, T, self.S), dtype=torch.float64, device=dev) if want_Y else None
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        nsteps = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        sums = torch.empty((B, 3), dtype=torch.float64, device=dev)
+        F = torch.empty((B, 3), dtype=torch.float64, device=dev)
+        lam = (C.c_double * 4)(*[float(v) for v in lambdas])
+        opts = _capi.default_opts(rtol=rtol, atol=atol, max_steps=max_steps, err_norm=err_norm)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self.ctx.lib.pk_network_simulate_objective_batch(self.ctx.handle, self._h, loss, B, _ptr(xd), int(raw), _ptr(yd), yb, th.ctypes.data, T,
+                                                              C.byref(opts), int(loss_mode), _ptr(dd), C.cast(lam, C.c_void_p), float(fail_value),
+                                                              _ptr(Y), _ptr(status), _ptr(nsteps), _ptr(sums), _ptr(F))
+        if rc == _capi.PK_ERR_UNSUPPORTED:
+            return None
+        self.ctx.check(rc)
+        F._keepalive = (xd, yd, dd)  # type: ignore[attr-defined]
+        return sums, F, status, nsteps, Y
+
     def resolved_method(self, method: str = "auto", kernel: str = "auto") -> str:
         """The integrator ``simulate_batch(method=, kernel=)`` will run on this network -- "ark", "rosw" or "dp5" -- as decided by the
         library itself (``pk_network_resolve_method``: network size, sites per protein AND the LDS footprint of the order-4 kernel).

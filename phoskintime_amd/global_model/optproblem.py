@@ -37,12 +37,21 @@ class GlobalODEBatch:
         # "rms": ODEPACK's norm (what the reference's LSODA controls): 1.4-1.7x fewer steps, but up to 2 parity band-widths off on
         # combinatorial populations (tests/test_gpu_network.py) -- opt-in only
         self.err_norm = err_norm
+        self.fused = None          # None: not asked yet; True / False: whether the library runs simulate + objective as one launch here
         self.xl, self.xu = xl, xu
         self.n_var, self.n_obj = eng.n_var, 3
 
     def evaluate_device(self, X) -> torch.Tensor:
-        """X [b, n_var] raw (softplus space, params.py:106-132; numpy or a GPU tensor) -> F [b, 3] as a GPU tensor: ONE simulate launch +
-        ONE loss launch, nothing returns to the host."""
+        """X [b, n_var] raw (softplus space, params.py:106-132; numpy or a GPU tensor) -> F [b, 3] as a GPU tensor, nothing returns to the
+        host.  ONE launch where the integrator can score the observations itself (arrow topologies on the default integrator: no
+        trajectory in HBM), else one simulate launch + one loss launch."""
+        if self.fused is not False:
+            out = self.eng.simulate_objective_batch(self.loss, X, self.time_grid, y0=self.y0, raw=True, rtol=self.rtol, atol=self.atol,
+                                                    max_steps=self.max_steps * self.time_grid.size, err_norm=self.err_norm, loss_mode=self.loss_mode,
+                                                    defaults=self.defaults, lambdas=self.lam, fail_value=self.fail_value)
+            self.fused = out is not None                        # the library's answer for this network / loss data: asked once
+            if out is not None:
+                return out[1]
         Y, status, _ = self.eng.simulate_batch(X, self.time_grid, y0=self.y0, raw=True, rtol=self.rtol, atol=self.atol,
                                                max_steps=self.max_steps * self.time_grid.size, err_norm=self.err_norm)
         _, F = self.eng.objective_batch(self.loss, Y, loss_mode=self.loss_mode, x=X, raw=True, defaults=self.defaults, lambdas=self.lam,

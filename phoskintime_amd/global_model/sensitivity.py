@@ -63,14 +63,29 @@ def _compute_scalar_metric(df_prot, df_rna, df_phos, metric="total_signal"):
 
 
 def scalar_metric_batch(pred: torch.Tensor, metric: str = "total_signal") -> torch.Tensor:
-    """_compute_scalar_metric over the rows of pred [B, n_obs] (GPU)."""
+    """_compute_scalar_metric over the rows of pred [B, n_obs] (GPU).  The row sums run as a fixed pairwise tree over the columns
+    (elementwise adds of column halves): a row's value does not depend on how many rows share the launch -- a library reduction picks its
+    split by the whole shape, and a rank that owns half the rows would then round differently from the one-process run."""
+    def rowsum(a: torch.Tensor) -> torch.Tensor:
+        n = a.shape[1]
+        if n == 0:
+            return a.new_zeros(a.shape[0])
+        m = 1 << (n - 1).bit_length()
+        if m != n:
+            a = torch.cat([a, a.new_zeros(a.shape[0], m - n)], dim=1)
+        while m > 1:
+            m >>= 1
+            a = a[:, :m] + a[:, m:]
+        return a[:, 0]
+    n = max(pred.shape[1], 1)
     if metric == "mean":
-        return pred.mean(dim=1)
+        return rowsum(pred) / n
     if metric == "variance":
-        return pred.var(dim=1, unbiased=False)
+        mu = rowsum(pred) / n
+        return rowsum((pred - mu[:, None]) ** 2) / n
     if metric == "l2_norm":
-        return torch.linalg.vector_norm(pred, dim=1)
-    return pred.sum(dim=1)
+        return torch.sqrt(rowsum(pred * pred))
+    return rowsum(pred)
 
 
 def run_sensitivity_batch(eng: NetworkEngine, fitted_params: Dict, times_p, times_r, times_ph, perturbation: float = config.SENSITIVITY_PERTURBATION,

@@ -856,3 +856,91 @@ def test_dense_lane_layout_of_the_additive_integrator_against_the_thread_per_pro
             assert np.max(np.abs(ns.sum(axis=1) - no.sum(axis=1))) <= 0.02 * no.sum(axis=1).max() + 2, (key, tag)
         np.testing.assert_array_equal(res["diet"][key + "_ns"], res["regs"][key + "_ns"])  # the two pair kernels: the same arithmetic
         np.testing.assert_array_equal(res["diet"][key + "_Y"], res["regs"][key + "_Y"])
+
+
+@pytest.mark.parametrize("name", ["network_m0_small", "network_m4_small", "netlarge_m0", "netlarge_m4"])
+def test_fused_simulate_objective_equals_the_two_launch_path(name):
+    """[r3] VERDICT r2 item 4 (iii) / SURVEY fused op (i): ``pk_network_simulate_objective_batch`` -- the integrator scores the observations
+    at its output times, no trajectory in HBM -- against ``simulate_batch`` + ``objective_batch`` on the same candidates: the same loss
+    sums and objectives for all eight LOSS_MODEs (up to the order of the sums), the reference's production baselines (protein / phospho at
+    t = 0, rna at t = 4: runner.py:545-547), raw and physical candidates, the prior term, a candidate that fails (fail_value in every
+    objective), batched y0, and the optional trajectory.  Loss data the fused path cannot take answer None (PK_ERR_UNSUPPORTED)."""
+    import torch
+    from phoskintime_amd.global_model import NetworkEngine
+    g = np.load(Path(__file__).resolve().parent / "golden" / f"{name}.npz")
+    eng = NetworkEngine.from_npz(g)
+    t = g["t_eval"]
+    K = g["c_k"].shape[0]
+    rng = np.random.default_rng(3)
+    X = np.stack([_x(eng, g, k % K) for k in range(6)]) * np.exp(0.3 * rng.standard_normal((6, eng.n_var)))
+    X[5, eng.n_K + eng.N: eng.n_K + 2 * eng.N] = np.nan                 # B_i = NaN: this candidate must come back as fail_value
+    lists, ld = eng.make_index_lists(t, t, t[t >= 4.0], t)               # every protein / site at every time of its modality, rna from t = 4
+    eng.free_loss(lists)
+    assert ld["rna_base_idx"] > 0 and ld["prot_base_idx"] == 0
+    for k in ("obs_prot", "obs_rna", "obs_pho"):
+        ld[k] = np.abs(1.0 + 0.2 * rng.standard_normal(ld[k].size))
+    for k in ("w_prot", "w_rna", "w_pho"):
+        ld[k] = rng.uniform(0.5, 2.0, ld[k].size)
+    loss = eng.make_loss(ld, t.size)
+    defaults = X[0] * 1.1
+    lam = (1.0, 0.5, 2.0, 0.7)
+    opt = dict(rtol=1e-8, atol=1e-8)
+    Y, st, ns = eng.simulate_batch(X, t, **opt)
+    assert int(st[5]) != 0 and not st[:5].cpu().numpy().any()
+    for mode in range(8):
+        s2, F2 = eng.objective_batch(loss, Y, loss_mode=mode, x=X, defaults=defaults, lambdas=lam, status=st)
+        out = eng.simulate_objective_batch(loss, X, t, loss_mode=mode, defaults=defaults, lambdas=lam, want_Y=(mode == 0), **opt)
+        assert out is not None
+        s1, F1, st1, ns1, Y1 = out
+        np.testing.assert_array_equal(st1.cpu().numpy(), st.cpu().numpy()); np.testing.assert_array_equal(ns1.cpu().numpy(), ns.cpu().numpy())
+        np.testing.assert_allclose(s1.cpu().numpy()[:5], s2.cpu().numpy()[:5], rtol=1e-11, equal_nan=True)
+        np.testing.assert_allclose(F1.cpu().numpy(), F2.cpu().numpy(), rtol=1e-11, equal_nan=True)
+        assert (F1[5].cpu().numpy() == 1e12).all()
+        if mode == 0:
+            np.testing.assert_array_equal(Y1.cpu().numpy()[:5], Y.cpu().numpy()[:5])
+    # raw candidates + batched initial states
+    Xraw = np.log(np.expm1(np.maximum(X[:5], 1e-12)))
+    y0b = np.tile(g["y0"], (5, 1)) * rng.uniform(0.8, 1.2, size=(5, eng.S))
+    Yb, stb, _ = eng.simulate_batch(Xraw, t, y0=y0b, raw=True, **opt)
+    _, Fb2 = eng.objective_batch(loss, Yb, x=Xraw, raw=True, defaults=defaults, lambdas=lam, status=stb)
+    _, Fb1, _, _, none = eng.simulate_objective_batch(loss, Xraw, t, y0=y0b, raw=True, defaults=defaults, lambdas=lam, **opt)
+    assert none is None
+    np.testing.assert_allclose(Fb1.cpu().numpy(), Fb2.cpu().numpy(), rtol=1e-11)
+    eng.free_loss(loss)
+    # an rna observation before its baseline, or a (state, time) observed twice: not fusable -- the caller falls back
+    ld2 = dict(ld); ld2["t_rna"] = ld["t_rna"].copy(); ld2["t_rna"][0] = 0
+    l2 = eng.make_loss(ld2, t.size)
+    assert eng.simulate_objective_batch(l2, X[:2], t, **opt) is None
+    eng.free_loss(l2)
+    ld3 = {k: (np.concatenate([v, v[:1]]) if k.endswith("_prot") and isinstance(v, np.ndarray) else v) for k, v in ld.items()}
+    l3 = eng.make_loss(ld3, t.size)
+    assert eng.simulate_objective_batch(l3, X[:2], t, **opt) is None
+    _, F3 = eng.objective_batch(l3, Y[:2], x=X[:2], defaults=defaults, lambdas=lam)     # ... and the two-launch path still takes them
+    assert np.isfinite(F3.cpu().numpy()).all()
+    eng.free_loss(l3)
+    eng.close()
+
+
+def test_fused_objective_is_what_the_optimisation_problem_runs():
+    """GlobalODEBatch.evaluate_device takes the fused launch where the library offers it (distributive topology) and the two-launch path
+    elsewhere (sequential: the thread-per-protein kernel) -- same F either way."""
+    import torch
+    from phoskintime_amd.global_model import NetworkEngine
+    from phoskintime_amd.global_model.optproblem import GlobalODEBatch
+    for name, fused in (("network_m0_small", True), ("network_m1_small", False)):
+        g = np.load(Path(__file__).resolve().parent / "golden" / f"{name}.npz")
+        eng = NetworkEngine.from_npz(g)
+        t = g["t_eval"]
+        lists, ld = eng.make_index_lists(t, t, t[t >= 4.0], t)
+        eng.free_loss(lists)
+        base = _x(eng, g, 0)
+        keys = ("c_k", "A_i", "B_i", "C_i", "D_i", "Dp_i", "E_i")
+        defaults = {k: g[k][0] for k in keys}; defaults["tf_scale"] = float(g["tf_scale"][0])
+        prob = GlobalODEBatch(eng, None, ld, defaults, {"protein": 1.0, "rna": 1.0, "phospho": 1.0, "prior": 0.01}, t, rtol=1e-8, atol=1e-8)
+        X = np.log(np.expm1(base[None, :] * np.exp(0.3 * np.random.default_rng(1).standard_normal((8, base.size)))))
+        F = prob.evaluate_device(X).cpu().numpy()
+        assert prob.fused is fused
+        Y, st, _ = eng.simulate_batch(X, t, raw=True, rtol=1e-8, atol=1e-8, max_steps=prob.max_steps * t.size)
+        _, F2 = eng.objective_batch(prob.loss, Y, x=X, raw=True, defaults=prob.defaults, lambdas=prob.lam, status=st)
+        np.testing.assert_allclose(F, F2.cpu().numpy(), rtol=1e-11)
+        prob.close(); eng.close()
