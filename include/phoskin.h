@@ -334,6 +334,21 @@ double pk_measure_hbm_gbs(pk_ctx*, int64_t bytes, int iters);
 double pk_measure_hbm_stream_gbs(pk_ctx*, int64_t bytes, int iters, int mode);
 double pk_measure_fp64_fma_tflops(pk_ctx*, int iters);
 
+/* ---- multi-GPU for an embedder without torch.distributed: one process per GPU, each rank integrates ITS rows with the
+ * batch entry points above and gathers the per-row results with ONE all-gather (RCCL over xGMI, on the context's stream) -- candidates /
+ * replicas never move.  Rank 0 makes an id (pk_comm_unique_id), the embedder ships its PK_COMM_ID_BYTES to every rank by its own means
+ * (MPI, a file, a socket), every rank calls pk_comm_init(ctx, id, rank, world); pk_allgather_f64(ctx, send, count, recv): send [count],
+ * recv [world * count] DEVICE pointers, rank r's block at recv + r * count.  Interleave rows as phoskintime_amd/distributed.py does
+ * (rank = position mod world in decreasing order of a cost proxy) to balance step counts.  RCCL is bound at run time: PK_ERR_UNSUPPORTED
+ * when librccl cannot be loaded.  pk_destroy frees the communicator too. */
+#define PK_COMM_ID_BYTES 128
+int pk_comm_unique_id(pk_ctx*, char* id_out /* [PK_COMM_ID_BYTES] */);
+int pk_comm_init(pk_ctx*, const char* id /* [PK_COMM_ID_BYTES] */, int rank, int world);
+int pk_comm_rank(pk_ctx*);
+int pk_comm_world(pk_ctx*);
+int pk_allgather_f64(pk_ctx*, const double* send, int64_t count, double* recv);
+int pk_comm_destroy(pk_ctx*);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SYMBOLS = (
     "pk_network_create", "pk_network_destroy", "pk_network_n_states", "pk_network_n_var",
     "pk_network_rhs_batch", "pk_network_jacobian_batch", "pk_network_unpack_batch", "pk_network_simulate_batch",
     "pk_network_loss_create", "pk_network_loss_destroy", "pk_network_objective_batch", "pk_network_simulate_objective_batch", "pk_network_observables_batch", "pk_frechet_batch", "pk_loss_fn_batch_host", "pk_network_resolve_method",
+    "pk_comm_unique_id", "pk_comm_init", "pk_comm_rank", "pk_comm_world", "pk_allgather_f64", "pk_comm_destroy",
 )
 
 PK_OK, PK_ERR_ARG, PK_ERR_UNSUPPORTED, PK_ERR_HIP, PK_ERR_NOMEM = 0, -1, -2, -3, -4      # include/phoskin.h
@@ -142,6 +143,12 @@ def load():
     lib.pk_loss_fn_batch_host.restype = i32
     lib.pk_loss_fn_batch_host.argtypes = [vp, i32, i32, i64, vp, i32, i32, C.POINTER(LossData), vp, i32, vp]
     lib.pk_network_unpack_batch.restype = i32; lib.pk_network_unpack_batch.argtypes = [vp, vp, i64, vp, vp]
+    lib.pk_comm_unique_id.restype = i32; lib.pk_comm_unique_id.argtypes = [vp, C.c_char_p]
+    lib.pk_comm_init.restype = i32; lib.pk_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
+    lib.pk_comm_rank.restype = i32; lib.pk_comm_rank.argtypes = [vp]
+    lib.pk_comm_world.restype = i32; lib.pk_comm_world.argtypes = [vp]
+    lib.pk_allgather_f64.restype = i32; lib.pk_allgather_f64.argtypes = [vp, vp, i64, vp]
+    lib.pk_comm_destroy.restype = i32; lib.pk_comm_destroy.argtypes = [vp]
     lib.pk_score_fit_batch.restype = i32; lib.pk_score_fit_batch.argtypes = [vp, i64, vp, i32, vp, vp, i32, vp, vp]
     lib.pk_measure_hbm_gbs.restype = dbl; lib.pk_measure_hbm_gbs.argtypes = [vp, i64, i32]
     lib.pk_measure_hbm_stream_gbs.restype = dbl; lib.pk_measure_hbm_stream_gbs.argtypes = [vp, i64, i32, i32]

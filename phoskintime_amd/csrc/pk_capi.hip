@@ -149,6 +149,7 @@ pk_ctx* pk_create(int device_id) {
 
 void pk_destroy(pk_ctx* c) {
   if (!c) return;
+  (void)pk_comm_destroy(c);                      // the communicator of the C-ABI collective (pk_comm.hip), if this context owns one
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->stage.p) (void)hipFree(c->stage.p);
