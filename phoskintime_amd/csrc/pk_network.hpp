@@ -80,6 +80,16 @@ __device__ __forceinline__ double synth_rate_fast(const double Ai, const double 
   return Ai * net_rcp(1.0 + ts * fabs(u));
 }
 
+// [r3] synthesis rate of the integrator kernels from the raw TF input v0 = (TF . P_vec)_i / tf_deg_i: topologies 0 / 1 / 2 squash before
+// calculate_synthesis_rate squashes again -- s(s(v)) = v / (1 + 2 |v|) -- and the two branches of the rate share ONE reciprocal chain
+// (den = 1 + u + 1e-6 for u >= 0, 1 + ts |u| below): two v_rcp_f64 + Newton chains on the critical path of a stage instead of four
+__device__ __forceinline__ double synth_rate_squashed(const double Ai, const double ts, const double v0, const bool squash_twice) {
+  const double u = v0 * net_rcp(1.0 + (squash_twice ? 2.0 : 1.0) * fabs(v0));
+  const bool pos = u >= 0.0;
+  const double rden = net_rcp(pos ? 1.0 + u + 1e-6 : __builtin_fma(ts, fabs(u), 1.0));
+  return pos ? Ai * __builtin_fma(ts * u, rden, 1.0) : Ai * rden;
+}
+
 // the eight LOSS_MODE point losses (global_model/lossfn.py:28-110) and the floored fold change of LOSS_FN (floor 1e-9)
 __device__ __forceinline__ double point_loss(const int mode, double diff, const double obs, const double pred) {
   constexpr double EPS = 1e-9;

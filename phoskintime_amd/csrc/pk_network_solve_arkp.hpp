@@ -201,11 +201,7 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     buf ^= 1;
     // synthesis rate (calculate_synthesis_rate on the squashed TF input; models 0 / 1 / 2 squash twice: s(s(v)) = v / (1 + 2 |v|)), with ONE
     // reciprocal chain per squash / rate instead of one per branch: den = 1 + u + 1e-6 (u >= 0) or 1 + ts |u| (u < 0)
-    const double v0 = acc * tfdeg_inv;
-    const double u = v0 * net_rcp(1.0 + (MODEL != 4 ? 2.0 : 1.0) * fabs(v0));
-    const bool pos = u >= 0.0;
-    const double rden = net_rcp(pos ? 1.0 + u + 1e-6 : __builtin_fma(ts, fabs(u), 1.0));
-    const double synth = pos ? Ai * __builtin_fma(ts * u, rden, 1.0) : Ai * rden;
+    const double synth = synth_rate_squashed(Ai, ts, acc * tfdeg_inv, MODEL != 4);
     // lane A: row 0 = synth - B R (the generic row with S = 0, L = B, plus synth); row 1 = generic (-D P) + [C R - sumS q + E sum(sites)]
     double q = Pb, eP;
     if (MODEL == 4) {
