@@ -1,5 +1,5 @@
 // Instantiations + launcher of the order-4 network integrator in the dense two-lanes-per-protein layout (pk_network_solve_arkp.hpp):
-// arrow topologies 0 / 4, site classes 4 / 6 / 8 (3 / 4 / 5 rows per lane).
+// arrow topologies 0 / 4 (here) and the sequential chain 1 (pk_inst_net_arkc.hip), site classes 4 / 6 / 8 (3 / 4 / 5 rows per lane).
 #include <type_traits>
 #include "pk_network_solve_arkp.hpp"
 #include <cstdlib>
@@ -10,6 +10,9 @@ bool net_arkp_enabled() {
   static const bool on = [] { const char* v = getenv("PK_ARK_PAIR"); return !(v && v[0] == '0'); }();
   return on;
 }
+
+// the sequential chain's instantiations live in their own translation unit (pk_inst_net_arkc.hip: parallel hipcc)
+hipError_t launch_net_arkp_chain(const NetDev& n, const NetSolveArgs& a, int threads, size_t lds, bool park, int nrl, long long B, hipStream_t st);
 
 // PK_ARK_PAIR: 0 = round 2's kernel (one thread per protein), 1 = the pair layout out of registers (256 VGPRs, 2 waves / SIMD),
 // 3 = the pair layout on the register diet (168 VGPRs, 3 waves / SIMD)
@@ -26,6 +29,7 @@ hipError_t launch_net_arkp(const NetDev& n, const NetSolveArgs& a, int nnzT, int
   const bool park = arkp_mode() == 3;
   const size_t lds = net_solve_arkp_lds_bytes(n, nrl, threads, park);
   if (threads > 512 || lds > 160 * 1024) return hipErrorInvalidValue;
+  if (n.model == 1) return launch_net_arkp_chain(n, a, threads, lds, park, nrl, B, st);
 #define PK_ARKP(K, M, R)                                                                                                              \
   do {                                                                                                                                \
     if (lds > 64 * 1024) {                                  /* beyond the default dynamic-LDS limit: raise it (idempotent, cheap) */  \

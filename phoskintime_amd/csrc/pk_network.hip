@@ -166,7 +166,7 @@ pk_net* pk_network_create(pk_ctx* c, const pk_network_desc* d) {
   for (int i = 0; i < d->N; ++i) n->max_sites = std::max(n->max_sites, (int)d->n_sites[i]);
   n->kin_grid_host.assign(d->kin_grid, d->kin_grid + d->n_grid);
   v.lane_unit = nullptr; v.n_lanes = 0;
-  if ((d->model == 0 || d->model == 4) && n->max_sites <= 8) {
+  if ((d->model == 0 || d->model == 1 || d->model == 4) && n->max_sites <= 8) {
     // dense lane table: a lane holds (2 + site class) / 2 rows; proteins with more sites than fit beside mRNA and protein take a second lane
     const int cls = n->max_sites <= 4 ? 4 : n->max_sites <= 6 ? 6 : 8, nrl = (2 + cls) / 2;
     std::vector<int32_t> lanes;
@@ -305,7 +305,7 @@ static int net_simulate_impl(pk_ctx* c, pk_net* n, int64_t B, const double* x, i
     for (int k = 0; k < 3; ++k) a.loss_norm[k] = fused->loss_norm[k];
     const bool can = !dp5 && pk_network_resolve_method(n, &o) == PK_METHOD_ARK436 && n->d.lane_unit && n->d.n_lanes <= 512 && pk::net_arkp_enabled() &&
                      pk::net_arkp_fuses_loss();
-    if (!can) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "fused objective: arrow topologies (0, 4) on the default additive integrator only; "
+    if (!can) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "fused objective: topologies 0 / 1 / 4 on the default additive integrator only; "
                                                          "use pk_network_simulate_batch + pk_network_objective_batch");
   }
   if (hipSetDevice(pk_ctx_device(c)) != hipSuccess) return pk_ctx_fail(c, PK_ERR_HIP, "hipSetDevice");

@@ -27,7 +27,7 @@ struct NetDev {
   const int32_t *W_indptr, *W_indices; const double* W_data;
   const int32_t *TF_indptr, *TF_indices; const double* TF_data;
   const double* tf_deg; const int32_t* driver_map; const double* kin_grid; const double* kin_Kmat;
-  // dense lane layout of the additive integrator (pk_network_solve_arkp.hpp; arrow topologies with <= 8 sites, else null / 0):
+  // dense lane layout of the additive integrator (pk_network_solve_arkp.hpp; topologies 0 / 1 / 4 with <= 8 sites, else null / 0):
   // entry = (protein << 2) | (paired << 1) | half, pairs on (even, odd) lanes first, then the single-lane proteins
   const int32_t* lane_unit; int n_lanes;
 };

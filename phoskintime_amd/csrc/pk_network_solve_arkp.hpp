@@ -30,7 +30,9 @@ __host__ __device__ constexpr int arkp_park_stride(int rows_per_lane) { return (
 template <int MODEL, int NRL, bool PARK>
 __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSolveArgs& A) {
   using namespace ark436;
-  static_assert(MODEL == 0 || MODEL == 4, "arrow topologies only");
+  static_assert(MODEL == 0 || MODEL == 1 || MODEL == 4, "arrow topologies (0, 4) and the sequential chain (1)");
+  constexpr bool CHAIN = MODEL == 1;
+  constexpr int NL = NRL - 1;                         // a lane's last row: the interface to its partner in the chain layout
   extern __shared__ __align__(16) double lds[];
   const int N = n.N, S = n.S;
   double* Kt = lds;                       // [n_K]
@@ -38,7 +40,10 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   double* red = Pv + 2 * N;               // [24]
   // PARK: [thread][slot] with an ODD slot count per thread: one address VGPR + immediate offsets for any block size, and the lanes of a
   // ds_read_b64 / ds_write_b64 group fall on distinct banks (2 * odd * lane mod 64)
+  // arrow: loss coefficient, site rate, solve factor, R_5, R_6;  chain: lower / upper coupling, loss coefficient, multiplier, inverse pivot
+  // (its R_5, R_6 stay in registers: it has fewer scalars to keep)
   constexpr int P_LK = 0, P_SR = NRL, P_WV = 2 * NRL, P_R5 = 3 * NRL, P_R6 = 4 * NRL, P_LOSS = 5 * NRL, P_STRIDE = arkp_park_stride(NRL);
+  constexpr int P_CA = NRL, P_CB = 2 * NRL, P_CM = 3 * NRL, P_CD = 4 * NRL;
   double* rbase = red + 24;               // PARK: [N] the mRNA baselines of the fused objective (captured at the rna baseline's output time)
   double* const mypark = rbase + (PARK ? N : 0) + (size_t)threadIdx.x * P_STRIDE;
   auto pld = [&](int slot) __attribute__((always_inline)) { return mypark[slot]; };
@@ -82,7 +87,8 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   int sj[NRL]; bool valid[NRL]; double Lk[NRL], Sr[NRL];
 #pragma unroll
   for (int k = 0; k < NRL; ++k) {
-    const int j = hb ? (NRL - 2 + k) : (k - 2);
+    // lane B holds the next NRL sites; in the chain layout in REVERSE order, so that both lanes sweep towards their common interface
+    const int j = hb ? (CHAIN ? 2 * NRL - 3 - k : NRL - 2 + k) : (k - 2);
     const bool site = own && j >= 0 && j < ns;
     sj[k] = site ? j : -1;
     valid[k] = site || (la && k < 2);
@@ -154,6 +160,11 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   auto from_a = [&](double v) __attribute__((always_inline)) { const double o = dpp_mov<0xA0>(v); return hb ? o : v; };
 
   double sumS = 0.0;
+  double ca[NRL], cb[NRL], cm[NRL], cdi[NRL], cI = 0.0, denI = 1.0;      // chain layout only
+  auto CA = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_CA + k); else return ca[k]; };
+  auto CB = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_CB + k); else return cb[k]; };
+  auto CM = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_CM + k); else return cm[k]; };
+  auto CD = [&](int k) __attribute__((always_inline)) { if constexpr (PARK) return pld(P_CD + k); else return cdi[k]; };
   auto set_bucket = [&](const int jb) __attribute__((always_inline)) {
     __syncthreads();
     for (int k = tid; k < n.n_K; k += nt) Kt[k] = n.kin_Kmat[(size_t)k * n.n_grid + jb] * (A.x_is_raw ? softplus(xb[sl.ck + k]) : xb[sl.ck + k]);
@@ -163,10 +174,33 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     for (int k = 0; k < NRL; ++k) {
       double acc = 0.0;
       if (sj[k] >= 0) for (int q = n.W_indptr[ss + sj[k]]; q < n.W_indptr[ss + sj[k] + 1]; ++q) acc += n.W_data[q] * Kt[n.W_indices[q]];
-      if constexpr (PARK) pst(P_SR + k, acc); else Sr[k] = acc;
+      if constexpr (CHAIN) Sr[k] = acc;
+      else { if constexpr (PARK) pst(P_SR + k, acc); else Sr[k] = acc; }
       acc_all += acc;
     }
-    sumS = pair_sum(acc_all);
+    if constexpr (!CHAIN) sumS = pair_sum(acc_all);
+    else {
+      // sequential chain (models.py sequential_rhs): row of site j:  S_j [previous form] + E [next form] - (S_{j+1} + E + Dp_j + D) [own];
+      // protein row: C R + E s_0 - (D + S_0) P.  Per row in SWEEP order: ca = coupling to the row before, cb = to the row after (the last
+      // row's: to the partner's last row), L = own loss.  Invalid rows: all zero (they must not feed their neighbours' pivots)
+      const double sr_o = mP * dpp_mov<0xB1>(Sr[NL]);                     // the partner's last row's site rate (lane A's last site needs S_{j+1})
+#pragma unroll
+      for (int k = 0; k < NRL; ++k) {
+        double a_, b_, l_;
+        const double lbase = (sj[k] >= 0) ? Ei + par(sl.Dp + ss + sj[k]) + Di : 0.0;
+        if (hb) {                                                         // sites in reverse order: the row before is the NEXT site
+          a_ = (k >= 1 && valid[k]) ? Ei : 0.0;
+          b_ = Sr[k];
+          l_ = lbase + (k >= 1 ? Sr[k - 1] : 0.0);
+        } else {
+          a_ = (k == 1) ? Ci : (k >= 2 ? Sr[k] : 0.0);
+          b_ = (k >= 1 && valid[k]) ? (k == NL ? mP * Ei : Ei) : 0.0;
+          l_ = (k == 0) ? Bi : (k == 1) ? Di + Sr[2 < NRL ? 2 : NL] : lbase + (k < NL ? Sr[k + 1 < NRL ? k + 1 : NL] : sr_o);
+        }
+        if (!valid[k]) { a_ = 0.0; b_ = 0.0; l_ = 0.0; }
+        if constexpr (PARK) { pst(P_CA + k, a_); pst(P_CB + k, b_); pst(P_LK + k, l_); } else { ca[k] = a_; cb[k] = b_; Lk[k] = l_; }
+      }
+    }
   };
 
   // frozen block Jacobian of the step (entries that depend on y_n) and the factors of g I - A
@@ -202,6 +236,20 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     // synthesis rate (calculate_synthesis_rate on the squashed TF input; models 0 / 1 / 2 squash twice: s(s(v)) = v / (1 + 2 |v|)), with ONE
     // reciprocal chain per squash / rate instead of one per branch: den = 1 + u + 1e-6 (u >= 0) or 1 + ts |u| (u < 0)
     const double synth = synth_rate_squashed(Ai, ts, acc * tfdeg_inv, MODEL != 4);
+    if constexpr (CHAIN) {
+      // the chain is linear in the block: f = A Y + synth e_R, A tridiagonal across the two lanes (the rows after a lane's last one is the
+      // partner's last row)
+      const double Yo = dpp_mov<0xB1>(Y[NL]);
+#pragma unroll
+      for (int k = 0; k < NRL; ++k) {
+        double lin = -LK(k) * Y[k];
+        if (k >= 1) lin = __builtin_fma(CA(k), Y[k - 1 >= 0 ? k - 1 : 0], lin);
+        lin = __builtin_fma(CB(k), (k < NL) ? Y[k + 1 < NRL ? k + 1 : NL] : Yo, lin);
+        if constexpr (MATVEC) G[k] = lin;
+        f[k] = (k == 0) ? __builtin_fma(mA, synth, lin) : lin;
+      }
+      return;
+    }
     // lane A: row 0 = synth - B R (the generic row with S = 0, L = B, plus synth); row 1 = generic (-D P) + [C R - sumS q + E sum(sites)]
     double q = Pb, eP;
     if (MODEL == 4) {
@@ -225,6 +273,23 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
     }
   };
   auto freeze_factor = [&](const double g) __attribute__((always_inline)) {
+    if constexpr (CHAIN) {
+      // twisted factorisation: each lane eliminates along its own sweep (lane A downwards from the mRNA row, lane B -- reversed rows --
+      // upwards from the last site); the two last rows meet in a 2 x 2 system whose inverse pivot replaces the last row's
+      double dprev = 0.0, dl = 1.0;
+#pragma unroll
+      for (int k = 0; k < NRL; ++k) {
+        const double m = (k >= 1) ? CA(k) * dprev : 0.0;
+        const double d = (k >= 1) ? __builtin_fma(-m, CB(k - 1 >= 0 ? k - 1 : 0), g + LK(k)) : g + LK(k);
+        dprev = net_rcp(d);
+        if (k == NL) dl = d;
+        if constexpr (PARK) { pst(P_CM + k, m); if (k < NL) pst(P_CD + k, dprev); } else { cm[k] = m; if (k < NL) cdi[k] = dprev; }
+      }
+      const double di_o = dpp_mov<0xB1>(dprev), b_o = dpp_mov<0xB1>(CB(NL));
+      cI = CB(NL) * di_o;                                                 // 0 for a single lane (its interface coupling is 0)
+      denI = net_rcp(__builtin_fma(-cI, b_o, dl));
+      return;
+    }
     const bool sat = MODEL == 4;
     const double Pb = from_a(y[1]);
     gPv = sat ? net_rcp((1.0 + Pb) * (1.0 + Pb)) : 1.0;
@@ -242,6 +307,17 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
   };
   // x = (g I - A)^-1 r
   auto block_solve = [&](const double (&r)[NRL], double (&x)[NRL]) __attribute__((always_inline)) {
+    if constexpr (CHAIN) {
+      double rp[NRL];
+      rp[0] = r[0];
+#pragma unroll
+      for (int k = 1; k < NRL; ++k) rp[k] = __builtin_fma(CM(k), rp[k - 1], r[k]);
+      const double rpo = dpp_mov<0xB1>(rp[NL]);
+      x[NL] = __builtin_fma(cI, rpo, rp[NL]) * denI;
+#pragma unroll
+      for (int k = NL - 1; k >= 0; --k) x[k] = CD(k) * __builtin_fma(CB(k), x[k + 1], rp[k]);
+      return;
+    }
     double t[NRL];
 #pragma unroll
     for (int k = 0; k < NRL; ++k) t[k] = r[k] * WV(k);
@@ -291,11 +367,11 @@ __device__ __forceinline__ void net_solve_arkp_body(const NetDev& n, const NetSo
       double Y[NRL], w[NRL], v[NRL], R[4][NRL], sb[NRL], se[NRL];
       auto Rg = [&](auto ic, int k) __attribute__((always_inline)) {          // right-hand side R_{ii + 3}, row k
         constexpr int ii = decltype(ic)::value;
-        if constexpr (PARK && ii >= 2) return pld((ii == 2 ? P_R5 : P_R6) + k); else return R[ii][k];
+        if constexpr (PARK && !CHAIN && ii >= 2) return pld((ii == 2 ? P_R5 : P_R6) + k); else return R[ii][k];
       };
       auto Rs = [&](auto ic, int k, double x) __attribute__((always_inline)) {
         constexpr int ii = decltype(ic)::value;
-        if constexpr (PARK && ii >= 2) pst((ii == 2 ? P_R5 : P_R6) + k, x); else R[ii][k] = x;
+        if constexpr (PARK && !CHAIN && ii >= 2) pst((ii == 2 ? P_R5 : P_R6) + k, x); else R[ii][k] = x;
       };
       // ---- stage 1: Y_1 = y_n
       rhs_block(y, w, v, std::true_type{});

@@ -815,7 +815,7 @@ sys.path.insert(0, sys.argv[1])
 from phoskintime_amd.global_model import NetworkEngine, synthetic
 out = {}
 t = np.array([0.0, 0.5, 1.0, 2.0, 4.0, 8.0, 15.0, 30.0, 60.0, 120.0, 240.0, 480.0, 960.0])
-for model in (0, 4):
+for model in (0, 1, 4):
     for cap, N, sites in ((4, 40, 90), (6, 100, 330), (8, 70, 300), (8, 180, 640)):
         net = synthetic.make_network(N=N, total_sites=sites, n_K=20, n_tf_edges=3 * N, model=model, seed=7 + cap + N, max_sites=cap)
         eng = NetworkEngine(**net)
@@ -844,7 +844,7 @@ def test_dense_lane_layout_of_the_additive_integrator_against_the_thread_per_pro
         subprocess.run([sys.executable, "-c", _ARKP_SCRIPT, root, str(f)], check=True, env={**os.environ, **env}, timeout=600)
         res[tag] = np.load(f)
     keys = [k[:-2] for k in res["old"].files if k.endswith("_Y")]
-    assert len(keys) == 8
+    assert len(keys) == 12
     for key in keys:
         Yo, no = res["old"][key + "_Y"], res["old"][key + "_ns"]
         assert not res["old"][key + "_st"].any() and np.isfinite(Yo).all()
