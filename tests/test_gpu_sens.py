@@ -296,12 +296,12 @@ np.savez(sys.argv[2], **out)
 
 def test_rows_kernel_agrees_with_the_column_kernel(tmp_path):
     """The two sensitivity kernels are independent implementations (columns across lanes with O(S) in-lane solves vs rows across lanes
-    with cross-lane arrow / cyclic-reduction solves, chunked columns): at the sizes both cover (PK_SENS_ROWS=1 forces the rows kernel;
+    with cross-lane arrow / cyclic-reduction solves, chunked columns): at the sizes both cover (PK_SENS_ROWS=1 forces the rows kernel, =2 the column kernel;
     read once per process, hence child processes) they must agree far inside the tolerance both integrate to."""
     import os, subprocess, sys
     root = str(Path(__file__).resolve().parents[1])
     res = {}
-    for tag, env in (("cols", "0"), ("rows", "1")):
+    for tag, env in (("cols", "2"), ("rows", "1")):       # 2: the column kernel wherever it exists (n <= 14); 1: the rows kernel everywhere
         f = tmp_path / f"{tag}.npz"
         e = dict(os.environ, PK_SENS_ROWS=env)
         subprocess.run([sys.executable, "-c", _AB_SCRIPT, root, str(f)], check=True, env=e, timeout=600)
