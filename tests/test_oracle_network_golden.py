@@ -112,12 +112,13 @@ MORE = sorted((Path(__file__).resolve().parent / "golden").glob("netlarge_more_m
 
 def test_large_network_more_reference_runs_inventory():
     """tools/make_golden_network.py large_more: further parameter sets of the SAME four N = 100 networks, each integrated by the reference at
-    1e-12 -- the truth the GPU population tests compare with (written candidate by candidate, so the count may differ per topology)."""
+    1e-12 -- the truth the GPU population tests compare with: seven per topology, i.e. eight reference-run 1e-12 trajectories per network
+    with the fixture's own."""
     assert [f.name for f in MORE] == [f"netlarge_more_m{m}.npz" for m in (0, 1, 2, 4)]
     for f in MORE:
         q = np.load(f); g = np.load(f.parent / f"netlarge_m{int(q['model'])}.npz")
         K = int(q["done"])
-        assert K >= 3 and q["Y_tight"].shape == (K, 15, int(g["S"])) and np.isfinite(q["Y_tight"]).all()
+        assert K == 7 and q["Y_tight"].shape == (K, 15, int(g["S"])) and np.isfinite(q["Y_tight"]).all()
         np.testing.assert_array_equal(q["y0"], g["y0"]); np.testing.assert_array_equal(q["t_eval"], g["t_eval"])
         for k in range(K):
             np.testing.assert_array_equal(q["Y_tight"][k, 0], g["y0"])
