@@ -858,7 +858,7 @@ def test_dense_lane_layout_of_the_additive_integrator_against_the_thread_per_pro
         np.testing.assert_array_equal(res["diet"][key + "_Y"], res["regs"][key + "_Y"])
 
 
-@pytest.mark.parametrize("name", ["network_m0_small", "network_m4_small", "netlarge_m0", "netlarge_m4"])
+@pytest.mark.parametrize("name", ["network_m0_small", "network_m1_small", "network_m4_small", "netlarge_m0", "netlarge_m1", "netlarge_m4"])
 def test_fused_simulate_objective_equals_the_two_launch_path(name):
     """[r3] VERDICT r2 item 4 (iii) / SURVEY fused op (i): ``pk_network_simulate_objective_batch`` -- the integrator scores the observations
     at its output times, no trajectory in HBM -- against ``simulate_batch`` + ``objective_batch`` on the same candidates: the same loss
@@ -922,12 +922,12 @@ def test_fused_simulate_objective_equals_the_two_launch_path(name):
 
 
 def test_fused_objective_is_what_the_optimisation_problem_runs():
-    """GlobalODEBatch.evaluate_device takes the fused launch where the library offers it (distributive topology) and the two-launch path
-    elsewhere (sequential: the thread-per-protein kernel) -- same F either way."""
+    """GlobalODEBatch.evaluate_device takes the fused launch where the library offers it (distributive, sequential: the dense lane layout)
+    and the two-launch path elsewhere (combinatorial: the thread-per-protein kernel) -- same F either way."""
     import torch
     from phoskintime_amd.global_model import NetworkEngine
     from phoskintime_amd.global_model.optproblem import GlobalODEBatch
-    for name, fused in (("network_m0_small", True), ("network_m1_small", False)):
+    for name, fused in (("network_m0_small", True), ("network_m1_small", True), ("network_m2_small", False)):
         g = np.load(Path(__file__).resolve().parent / "golden" / f"{name}.npz")
         eng = NetworkEngine.from_npz(g)
         t = g["t_eval"]
