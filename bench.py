@@ -310,7 +310,7 @@ def main():
                                 "algorithmic_flops_per_launch": fl_launch, "peak_source": "spec sheet; measured value under peaks_measured"}
         # counters of this very kernel + workload from the committed rocprofv3 PMC passes (tools/profile_bench.sh): labelled as such,
         # and only attached when the run matches the profiled configuration
-        prof = sorted((ROOT / "profiles").glob("r02_*_config3_pmc.json")) or sorted((ROOT / "profiles").glob("r01_k_final_pmc.json"))
+        prof = sorted((ROOT / "profiles").glob("r0[2-9]_*_config3_pmc.json")) or sorted((ROOT / "profiles").glob("r01_k_final_pmc.json"))      # the latest round's
         if prof and args.method == "lrp12" and args.linsolve == "auto" and B == 65536 and (args.rtol, args.atol) == (1e-6, 1e-8):
             pj = json.loads(prof[-1].read_text())
             if pj.get("kernel") == kname:

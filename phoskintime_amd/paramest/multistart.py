@@ -100,8 +100,9 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     lambda scan at P = 64 (tools/gpu_fit_profile2.py): 390 of the fit's 394 ms, against 10 ms of Jacobian kernels.  "device": J^T J stays in
     HBM; masking, the damped solves of all damping levels (``torch.linalg.solve_ex``: the vendor's batched LU), the projection on the box
     and the predicted reductions are device ops, and only vectors (gradient, diagonal, trial points' costs: O(P) per row) cross PCIe.
-    "auto": device when rows x P^2 >= 2^17 and the residual algebra is on the device, else host (small fits are launch-bound: a dozen
-    tiny device ops per round cost more than numpy on 48 x 12 x 12 numbers)."""
+    "auto": device in every iteration whose ACTIVE rows x P^2 >= 2^17 (and the residual algebra is on the device), else host -- small
+    problems, and the late iterations of big ones, are launch-bound: a dozen tiny device ops per round cost more than numpy on
+    48 x 12 x 12 numbers (measured: 480 rows at P = 20, 60 iterations: 351 ms all-device, 261 ms all-host)."""
     import torch
     log_space = (model == "randmod")
     P0 = np.atleast_2d(np.asarray(P0, float))
@@ -132,7 +133,9 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         device_algebra = R * P * Nd * 8 > (2 << 20)                   # bytes of `flat` one Jacobian evaluation would move over PCIe
     if lm_algebra not in ("auto", "host", "device"):
         raise ValueError("lm_algebra must be 'auto', 'host' or 'device'")
-    lm_dev = (lm_algebra == "device") or (lm_algebra == "auto" and bool(device_algebra) and R * P * P >= (1 << 17))
+    # decided per iteration from the rows still active ("auto"): late iterations of a big fit are small, launch-bound problems again
+    lm_dev_ok = (lm_algebra == "device") or (lm_algebra == "auto" and bool(device_algebra) and R * P * P >= (1 << 17))
+    lm_dev = lm_dev_ok
     # per-fit constants go to HBM once (a host array handed to a launch is uploaded by that launch: 35 us each, several per iteration)
     t_d = torch.as_tensor(tfull, device=dev); isig_d = torch.as_tensor(1.0 / sig, device=dev); lam_d = torch.as_tensor(lam / P, device=dev)
     y0_d = torch.as_tensor(np.array(y0, dtype=float, copy=True), device=dev)
@@ -200,12 +203,13 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     mu = np.full(R, 1e-3)
     active = np.ones(R, bool)
     JTJ = np.zeros((R, P, P))
-    JTJ_d = torch.zeros((R, P, P), dtype=torch.float64, device=dev) if lm_dev else None
+    JTJ_d = torch.zeros((R, P, P), dtype=torch.float64, device=dev) if lm_dev_ok else None
     it = 0
     for it in range(1, max_iter + 1):
         idx = np.where(active)[0]
         if idx.size == 0:
             break
+        lm_dev = lm_dev_ok and (lm_algebra == "device" or idx.size * P * P >= (1 << 17))
         # forward-difference Jacobian (SciPy's '2-point' rule: h = sqrt(eps) * max(1, |p|), flipped at the upper bound)
         h = np.sqrt(np.finfo(float).eps) * np.maximum(1.0, np.abs(p[idx]))
         h = np.where(p[idx] + h > ub[idx], -h, h)
@@ -220,9 +224,9 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
                 r_at = torch.as_tensor(r[idx], device=dev)
             # J^T [J | r] in one product, one copy back: [k, P, P + 1]  (lm_algebra = device: only the gradient and the diagonal come back)
             AG_d = torch.bmm(Jd.transpose(1, 2), torch.cat([Jd, r_at[:, :, None]], dim=2))
-            if lm_dev:
+            if lm_dev_ok:
                 A_d, g_d = AG_d[:, :, :P].contiguous(), AG_d[:, :, P].contiguous()
-            else:
+            if not lm_dev:
                 AG = AG_d.cpu().numpy()
                 A, g = np.ascontiguousarray(AG[:, :, :P]), np.ascontiguousarray(AG[:, :, P])
         elif device_algebra:
@@ -238,10 +242,11 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
             Ja = np.transpose((rp - r[idx][:, None, :]) / h[:, :, None], (0, 2, 1))
             g = np.einsum("knp,kn->kp", Ja, r[idx])
             A = np.einsum("knp,knq->kpq", Ja, Ja)
-        if lm_dev:
+        if lm_dev_ok:
             if jacobian != "sens" and not device_algebra:                              # host residual algebra with device LM algebra: upload once
                 A_d, g_d = torch.as_tensor(A, device=dev), torch.as_tensor(g, device=dev)
-            JTJ_d[torch.as_tensor(idx, device=dev)] = A_d
+            JTJ_d[torch.as_tensor(idx, device=dev)] = A_d                              # what pcov needs stays in HBM until the end
+        if lm_dev:
             g = g_d.cpu().numpy()
             diagA = torch.diagonal(A_d, dim1=1, dim2=2).cpu().numpy()
             p_idx_d, lb_idx_d, ub_idx_d = (torch.as_tensor(np.ascontiguousarray(x[idx]), device=dev) for x in (p, lb, ub))
@@ -354,7 +359,7 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
             pend = pend[~ok]
         active[idx[pend]] = False          # no acceptable step within the damping budget: converged / stalled
     r_out = r_d.cpu().numpy() if device_algebra else r
-    if lm_dev:
+    if lm_dev_ok:
         JTJ = JTJ_d.cpu().numpy()
     return RowsFit(p=p, cost=cost, r=r_out, JTJ=JTJ, n_iter=it, n_solves=n_solves, n_launches=n_launches)
 
