@@ -143,13 +143,16 @@ __global__ __launch_bounds__(256) void rand_parity_kernel(const SolveArgs A) {
         constexpr int p = kk & 1;
         const int k = TS * kb + kk;
         double* rb = rowb + p * NM; double* cb = colb + p * NM;
-        if (prow) static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[TS * bj + jj] = a[kk][jj]; });
-        if (pcol) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[TS * bi + ii] = a[ii][kk]; });
+        // [r3] the published pivot row / column are stored TRANSPOSED (entry jj of block bj at [jj][bj]): the lanes of a wave then read 16
+        // consecutive doubles per entry.  In block order ([bj][jj], 64 B between the blocks) the sixteen distinct addresses of a read fell
+        // on two 16-byte bank groups -- 8-way conflicts on every one of the 8 + 8 reads of a pivot, 2 100 clocks per pivot for 450 of issue
+        if (prow) static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[jj * TB + bj] = a[kk][jj]; });
+        if (pcol) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[ii * TB + bi] = a[ii][kk]; });
         __syncthreads();
-        const double rp = fast_rcp(rb[k]);
+        const double rp = fast_rcp(rb[kk * TB + kb]);
         double rowv[TS], ml[TS];
-        static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[TS * bj + jj]; });
-        static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; ml[ii] = cb[TS * bi + ii] * rp; });
+        static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[jj * TB + bj]; });
+        static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; ml[ii] = cb[ii * TB + bi] * rp; });
         static_for<TS>([&](auto ic) {
           constexpr int ii = decltype(ic)::value;
           static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; a[ii][jj] = __builtin_fma(-ml[ii], rowv[jj], a[ii][jj]); });
@@ -171,11 +174,11 @@ __global__ __launch_bounds__(256) void rand_parity_kernel(const SolveArgs A) {
       for (int j = 0; j < NB; ++j) { const int bit = 1 << j, c = ma ^ bit; s = __builtin_fma(wgt(ma, bit) * dio[c], src[1 + c], s); }
       double r0 = src[1 + ma];
       if (ma == 0) r0 = __builtin_fma(qC, zR, r0);               // the -q C z_R coupling of the mask-0 row moved to the right-hand side
-      re[tid] = __builtin_fma(q, s, r0);
+      re[(tid % TS) * TB + tid / TS] = __builtin_fma(q, s, r0);      // transposed like the pivot buffers: conflict-free reads below
     }
     __syncthreads();
     double r[TS], pr[TS];
-    static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; r[jj] = re[TS * bj + jj]; });
+    static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; r[jj] = re[jj * TB + bj]; });
     static_for<TS>([&](auto ic) {
       constexpr int ii = decltype(ic)::value;
       double v = a[ii][0] * r[0];
