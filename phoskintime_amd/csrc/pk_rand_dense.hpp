@@ -117,13 +117,13 @@ __global__ __launch_bounds__(rand_dense_threads<NB>()) void rand_dense_kernel(co
         constexpr int p = kk & 1;
         const int k = 8 * kb + kk;
         double* rb = rowb + p * NM; double* cb = colb + p * NM;
-        if (prow) static_for<8>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[8 * bj + jj] = a[kk][jj]; });
-        if (pcol) static_for<8>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[8 * bi + ii] = a[ii][kk]; });
+        if (prow) static_for<8>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[jj * 16 + bj] = a[kk][jj]; });
+        if (pcol) static_for<8>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[ii * 16 + bi] = a[ii][kk]; });
         __syncthreads();
-        const double rp = fast_rcp(rb[k]);
+        const double rp = fast_rcp(rb[kk * 16 + kb]);                    // [r3] buffers transposed ([jj][bj]): conflict-free reads (pk_rand_parity.hpp)
         double rowv[8], ml[8];
-        static_for<8>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[8 * bj + jj]; });
-        static_for<8>([&](auto ic) { constexpr int ii = decltype(ic)::value; ml[ii] = cb[8 * bi + ii] * rp; });
+        static_for<8>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[jj * 16 + bj]; });
+        static_for<8>([&](auto ic) { constexpr int ii = decltype(ic)::value; ml[ii] = cb[ii * 16 + bi] * rp; });
         static_for<8>([&](auto ic) {
           constexpr int ii = decltype(ic)::value;
           static_for<8>([&](auto jc) { constexpr int jj = decltype(jc)::value; a[ii][jj] = __builtin_fma(-ml[ii], rowv[jj], a[ii][jj]); });

@@ -179,13 +179,14 @@ __global__ __launch_bounds__(256) void rand_sens_kernel(const SensArgs SA) {
         constexpr int p = kk & 1;
         const int k = TS * kb + kk;
         double* rb = rowb + p * NM; double* cb = colb + p * NM;
-        if (prow) static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[TS * bj + jj] = a[kk][jj]; });
-        if (pcl) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[TS * bi + ii] = a[ii][kk]; });
+        // pivot row / column published TRANSPOSED ([jj][bj]): conflict-free reads (pk_rand_parity.hpp has the measurement)
+        if (prow) static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[jj * TB + bj] = a[kk][jj]; });
+        if (pcl) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[ii * TB + bi] = a[ii][kk]; });
         __syncthreads();
-        const double rp = fast_rcp(rb[k]);
+        const double rp = fast_rcp(rb[kk * TB + kb]);
         double rowv[TS], ml[TS];
-        static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[TS * bj + jj]; });
-        static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; ml[ii] = cb[TS * bi + ii] * rp; });
+        static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[jj * TB + bj]; });
+        static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; ml[ii] = cb[ii * TB + bi] * rp; });
         static_for<TS>([&](auto ic) {
           constexpr int ii = decltype(ic)::value;
           static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; a[ii][jj] = __builtin_fma(-ml[ii], rowv[jj], a[ii][jj]); });
@@ -206,13 +207,13 @@ __global__ __launch_bounds__(256) void rand_sens_kernel(const SensArgs SA) {
       for (int j = 0; j < NB; ++j) { const int bit = 1 << j, mc = ma ^ bit; s = __builtin_fma(wgt(ma, bit) * dio[mc], src[(1 + mc) * KC + c], s); }
       double r0 = src[(1 + ma) * KC + c];
       if (ma == 0) { const double zR = src[c] * winvR; dst[c] = zR; r0 = __builtin_fma(qC, zR, r0); }
-      re[it] = __builtin_fma(q, s, r0);
+      re[c * NM + (e % TS) * TB + e / TS] = __builtin_fma(q, s, r0);     // [column][jj][bj]: the product below reads 16 consecutive doubles
     }
     __syncthreads();
     static_for<KC>([&](auto cc) {                                 // x_e = S_ee^-1 r'_e, column by column
       constexpr int c = decltype(cc)::value;
       double r[TS];
-      static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; r[jj] = re[(TS * bj + jj) * KC + c]; });
+      static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; r[jj] = re[c * NM + jj * TB + bj]; });
       static_for<TS>([&](auto ic) {
         constexpr int ii = decltype(ic)::value;
         double v = a[ii][0] * r[0];
