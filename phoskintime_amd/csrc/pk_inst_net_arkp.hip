@@ -23,6 +23,14 @@ static int arkp_mode() {
 
 bool net_arkp_fuses_loss() { return arkp_mode() == 3; }
 
+// does the dense lane layout take this network?  (lane table present, <= 512 lanes, LDS of the chosen variant within 160 KB)
+bool net_arkp_fits(const NetDev& n, int max_sites) {
+  if (!n.lane_unit || n.n_lanes < 1 || n.n_lanes > 512 || !net_arkp_enabled()) return false;
+  const int threads = ((n.n_lanes + 63) / 64) * 64;
+  const int nrl = arkp_rows_per_lane(max_sites <= 4 ? 4 : max_sites <= 6 ? 6 : 8);
+  return net_solve_arkp_lds_bytes(n, nrl, threads, arkp_mode() == 3) <= 160 * 1024;
+}
+
 hipError_t launch_net_arkp(const NetDev& n, const NetSolveArgs& a, int nnzT, int max_sites, long long B, hipStream_t st) {
   const int threads = ((n.n_lanes + 63) / 64) * 64;
   const int nrl = arkp_rows_per_lane(max_sites <= 4 ? 4 : max_sites <= 6 ? 6 : 8);

@@ -16,6 +16,7 @@ size_t net_ark_lds_bytes(const NetDev& n, int nnzT, int max_sites, int threads);
 hipError_t launch_net_ark(const NetDev& n, const NetSolveArgs& a, int max_sites, long long B, int threads, size_t lds, hipStream_t st);
 // the same method in the dense two-lanes-per-protein layout (pk_network_solve_arkp.hpp; arrow topologies): n.lane_unit must be set
 bool net_arkp_enabled();
+bool net_arkp_fits(const NetDev& n, int max_sites);
 bool net_arkp_fuses_loss();                      // the register-diet kernel (PK_ARK_PAIR=3, the default) scores observations at its output times
 hipError_t launch_net_arkp(const NetDev& n, const NetSolveArgs& a, int nnzT, int max_sites, long long B, hipStream_t st);
 }
@@ -303,8 +304,7 @@ static int net_simulate_impl(pk_ctx* c, pk_net* n, int64_t B, const double* x, i
     a.loss_fail = fused->loss_fail; a.loss_sums = fused->loss_sums; a.loss_F = fused->loss_F; a.loss_rna_base = fused->loss_rna_base;
     for (int k = 0; k < 4; ++k) a.loss_lam[k] = fused->loss_lam[k];
     for (int k = 0; k < 3; ++k) a.loss_norm[k] = fused->loss_norm[k];
-    const bool can = !dp5 && pk_network_resolve_method(n, &o) == PK_METHOD_ARK436 && n->d.lane_unit && n->d.n_lanes <= 512 && pk::net_arkp_enabled() &&
-                     pk::net_arkp_fuses_loss();
+    const bool can = !dp5 && pk_network_resolve_method(n, &o) == PK_METHOD_ARK436 && pk::net_arkp_fits(n->d, n->max_sites) && pk::net_arkp_fuses_loss();
     if (!can) return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "fused objective: topologies 0 / 1 / 4 on the default additive integrator only; "
                                                          "use pk_network_simulate_batch + pk_network_objective_batch");
   }
@@ -368,7 +368,7 @@ static int net_simulate_impl(pk_ctx* c, pk_net* n, int64_t B, const double* x, i
       static const double ctl_g = [] { const char* v = getenv("PK_ARK_GROW"); return v ? atof(v) : 0.0; }();
       aa.ctl_safety = ctl_s; aa.ctl_grow = ctl_g;
       // [r3] arrow topologies: the dense two-lanes-per-protein layout, every stage vector in registers (PK_ARK_PAIR=0: round 2's kernel)
-      const bool pair = n->d.lane_unit && n->d.n_lanes <= 512 && pk::net_arkp_enabled();
+      const bool pair = pk::net_arkp_fits(n->d, n->max_sites);
       hipError_t ea = pair ? pk::launch_net_arkp(n->d, aa, n->nnzT, n->max_sites, (long long)B, stream)
                            : pk::launch_net_ark(n->d, aa, n->max_sites, (long long)B, threads_a, lds_a, stream);
       if (ea == hipSuccess) ea = hipGetLastError();
