@@ -247,7 +247,9 @@ int pk_network_resolve_method(const pk_net* n, const pk_solver_opts* opts) {
   if (method == PK_METHOD_DP5) return PK_METHOD_DP5;
   const int threads_a = ((n->d.N + 63) / 64) * 64;
   const bool ark_fits = n->d.N <= 256 && n->max_sites <= (n->d.model == 2 ? 3 : 8) && linsolve != PK_LINSOLVE_STRUCTURED;
-  const bool ark_ok = ark_fits && pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) <= 160 * 1024;
+  // one thread per protein (N <= 256), or [r3] the dense lane layout of topologies 0 / 1 / 4 (<= 512 lanes: up to 512 proteins)
+  const bool ark_ok = (ark_fits && pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) <= 160 * 1024) ||
+                      (linsolve != PK_LINSOLVE_STRUCTURED && pk::net_arkp_fits(n->d, n->max_sites));
   if (method == PK_METHOD_ARK436) return ark_ok ? PK_METHOD_ARK436 : PK_ERR_UNSUPPORTED;
   // [r3] the combinatorial topology takes the additive method by default too: with the EXACT block solve (parity elimination of the
   // bit-pattern block, pk_network_solve_ark.hpp) it needs 4.6x fewer steps than the order-3 method and runs 1.8x faster at equal band error
@@ -350,7 +352,8 @@ static int net_simulate_impl(pk_ctx* c, pk_net* n, int64_t B, const double* x, i
     const int threads_a = ((n->d.N + 63) / 64) * 64;
     const int resolved = pk_network_resolve_method(n, &o);
     if (resolved == PK_ERR_UNSUPPORTED)
-      return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "PK_METHOD_ARK436: N <= 256 and <= 8 sites per protein (combinatorial topology: <= 3); use PK_METHOD_ROS34PW2");
+      return pk_ctx_fail(c, PK_ERR_UNSUPPORTED, "PK_METHOD_ARK436: <= 8 sites per protein and N <= 256 (topologies 0 / 1 / 4: <= 512 lanes of the dense layout); "
+                                                "combinatorial topology: <= 3 sites, N <= 256; use PK_METHOD_ROS34PW2");
     const size_t lds_a = resolved == PK_METHOD_ARK436 ? pk::net_ark_lds_bytes(n->d, n->nnzT, n->max_sites, threads_a) : 0;
     if (resolved == PK_METHOD_ARK436) {
       // The order-4 method runs at 0.25 x the requested tolerances: at that factor its error equals the order-3 method's at the SAME nominal

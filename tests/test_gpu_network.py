@@ -944,3 +944,23 @@ def test_fused_objective_is_what_the_optimisation_problem_runs():
         _, F2 = eng.objective_batch(prob.loss, Y, x=X, raw=True, defaults=prob.defaults, lambdas=prob.lam, status=st)
         np.testing.assert_allclose(F, F2.cpu().numpy(), rtol=1e-11)
         prob.close(); eng.close()
+
+
+def test_dense_lane_layout_takes_networks_beyond_256_proteins():
+    """The thread-per-protein kernel stops at N = 256; the dense lane layout is bounded by its 512 lanes -- a 300-protein network (1 000
+    states) runs the order-4 method by default now.  Against the order-3 Rosenbrock-W (the only integrator such a network had) at a
+    tighter tolerance: inside the band, at a fraction of the steps."""
+    from phoskintime_amd.global_model import NetworkEngine, synthetic
+    for model in (0, 1):
+        net = synthetic.make_network(N=300, total_sites=400, n_K=30, n_tf_edges=700, model=model, seed=11, max_sites=4)
+        eng = NetworkEngine(**net)
+        assert eng.N == 300 and eng.S == 1000 and eng.resolved_method() == "ark"
+        X = synthetic.random_candidates(net, 12, seed=2, spread=0.5)
+        t = np.array([0.0, 1.0, 4.0, 15.0, 60.0, 240.0, 960.0])
+        Ya, sa, na = eng.simulate_batch(X, t, rtol=1e-8, atol=1e-8)
+        Yr, sr, nr = eng.simulate_batch(X, t, rtol=1e-9, atol=1e-10, method="rosw")
+        assert not sa.cpu().numpy().any() and not sr.cpu().numpy().any()
+        band = float(((Ya - Yr).abs() / (1e-8 + 1e-6 * Yr.abs())).max())
+        assert band <= 0.2, band
+        assert (3 * na[:, 0].cpu().numpy() <= nr[:, 0].cpu().numpy()).all()
+        eng.close()
