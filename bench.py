@@ -515,7 +515,7 @@ def lm_leg():
             modes.insert(1, ("forward_sensitivities_host_lm_round2", "auto", "sens", "host"))
         for name, dev_alg, jac, lm in modes:
             fit_rows_batch("distmod", n, TGRID, P0[:4], np.ones(S), target, bounds=(lb, ub), max_iter=2, device_algebra=dev_alg, jacobian=jac, lm_algebra=lm)
-            if lm == "auto" and rows * P * P >= (1 << 17):                               # warm the batched-LU path at its real shape
+            if lm == "auto" and rows * P * P >= (1 << 19):                               # warm the batched-LU path at its real shape
                 fit_rows_batch("distmod", n, TGRID, P0, np.ones(S), target, bounds=(lb, ub), max_iter=1, device_algebra=dev_alg, jacobian=jac, lm_algebra=lm)
             torch.cuda.synchronize()
             t1 = time.perf_counter()

@@ -100,7 +100,7 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     lambda scan at P = 64 (tools/gpu_fit_profile2.py): 390 of the fit's 394 ms, against 10 ms of Jacobian kernels.  "device": J^T J stays in
     HBM; masking, the damped solves of all damping levels (``torch.linalg.solve_ex``: the vendor's batched LU), the projection on the box
     and the predicted reductions are device ops, and only vectors (gradient, diagonal, trial points' costs: O(P) per row) cross PCIe.
-    "auto": device in every iteration whose ACTIVE rows x P^2 >= 2^17 (and the residual algebra is on the device), else host -- small
+    "auto": device in every iteration whose ACTIVE rows x P^2 >= 2^19 (and the residual algebra is on the device), else host -- small
     problems, and the late iterations of big ones, are launch-bound: a dozen tiny device ops per round cost more than numpy on
     48 x 12 x 12 numbers (measured: 480 rows at P = 20, 60 iterations: 351 ms all-device, 261 ms all-host)."""
     import torch
@@ -134,7 +134,7 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
     if lm_algebra not in ("auto", "host", "device"):
         raise ValueError("lm_algebra must be 'auto', 'host' or 'device'")
     # decided per iteration from the rows still active ("auto"): late iterations of a big fit are small, launch-bound problems again
-    lm_dev_ok = (lm_algebra == "device") or (lm_algebra == "auto" and bool(device_algebra) and R * P * P >= (1 << 17))
+    lm_dev_ok = (lm_algebra == "device") or (lm_algebra == "auto" and bool(device_algebra) and R * P * P >= (1 << 19))
     lm_dev = lm_dev_ok
     # per-fit constants go to HBM once (a host array handed to a launch is uploaded by that launch: 35 us each, several per iteration)
     t_d = torch.as_tensor(tfull, device=dev); isig_d = torch.as_tensor(1.0 / sig, device=dev); lam_d = torch.as_tensor(lam / P, device=dev)
@@ -209,7 +209,7 @@ def fit_rows_batch(model: str, num_psites: int, time_points, P0, init_cond, targ
         idx = np.where(active)[0]
         if idx.size == 0:
             break
-        lm_dev = lm_dev_ok and (lm_algebra == "device" or idx.size * P * P >= (1 << 17))
+        lm_dev = lm_dev_ok and (lm_algebra == "device" or idx.size * P * P >= (1 << 19))
         # forward-difference Jacobian (SciPy's '2-point' rule: h = sqrt(eps) * max(1, |p|), flipped at the upper bound)
         h = np.sqrt(np.finfo(float).eps) * np.maximum(1.0, np.abs(p[idx]))
         h = np.where(p[idx] + h > ub[idx], -h, h)
