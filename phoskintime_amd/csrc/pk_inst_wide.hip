@@ -45,6 +45,13 @@ hipError_t launch_rand_level(const SolveArgs& a_in, hipStream_t st) {
 hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st) {
   if (a.n_sites == 8) hipLaunchKernelGGL(rand_parity_kernel<8>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(8), st, a);
   else if (a.n_sites == 7) hipLaunchKernelGGL(rand_parity_kernel<7>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(7), st, a);
+  else if (a.n_sites == 6) {
+    // PK_RAND_PARITY6_TB=16 (dev, read once): the 256-thread grid (2 x 2 blocks) instead of one wave per replica (8 x 8 lanes, 4 x 4 blocks)
+    static const bool wide6 = [] { const char* v = getenv("PK_RAND_PARITY6_TB"); return v && atoi(v) == 16; }();
+    if (wide6) hipLaunchKernelGGL((rand_parity_kernel<6, 16>), dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(6), st, a);
+    else       hipLaunchKernelGGL((rand_parity_kernel<6, 8>), dim3((unsigned)a.B), dim3(64), rand_parity_lds_bytes(6), st, a);
+  }
+  else if (a.n_sites == 5) hipLaunchKernelGGL(rand_parity_kernel<5>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(5), st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

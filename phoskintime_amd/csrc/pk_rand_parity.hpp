@@ -29,12 +29,14 @@ constexpr size_t rand_parity_lds_bytes(int n) {
   return (5 * (NALL + 1) + 3 * NALL + 4 * NM + NM + (2 + n) + 24) * sizeof(double);
 }
 
-template <int NB>
-__global__ __launch_bounds__(256) void rand_parity_kernel(const SolveArgs A) {
-  static_assert(NB == 7 || NB == 8, "a 16 x 16 thread grid over the even Schur complement: 4 x 4 blocks (n = 7) or 8 x 8 blocks (n = 8)");
+// TBP: side of the thread grid over the even Schur complement.  16 (256 threads: n = 7, 8) or 8 (64 threads = ONE wave per replica: n = 6,
+// 4 x 4 blocks per lane, every workgroup barrier is a single wave's)
+template <int NB, int TBP = 16>
+__global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs A) {
+  static_assert(NB >= 5 && NB <= 8 && (TBP == 16 || TBP == 8) && (1 << NB) <= TBP * TBP, "thread grid over the even Schur complement (one thread per bit mask in the set-up loops)");
   constexpr int NALL = 1 << NB;
   using Tab = ResolventTab<PK_METHOD_LRP12>;
-  constexpr int NM = NALL / 2, TB = 16, TS = NM / TB, NT = TB * TB;   // NM even states: the dense core, a TS x TS block per thread
+  constexpr int NM = NALL / 2, TB = TBP, TS = NM / TB, NT = TB * TB;   // NM even states: the dense core, a TS x TS block per thread
   extern __shared__ __align__(16) double lds[];
   const int tid = threadIdx.x, nt = NT;
   const int bi = tid / TB, bj = tid % TB, lane = tid & 63;

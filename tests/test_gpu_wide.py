@@ -303,17 +303,21 @@ def test_exact_randmod_kernels_agree_with_each_other_and_the_closed_form(tmp_pat
     """Three independent exact implementations per size, selected per process (PK_WIDE_RAND_EXACT / PK_RAND_LEVEL6 are read once):
       n = 8: parity elimination (default) vs block elimination over the popcount levels (csrc/pk_rand_level.hpp)
       n = 7: parity elimination (default) vs the full 128 x 128 inverse in registers (csrc/pk_rand_dense.hpp, round 2)
-      n = 6: the one-wave kernel (default) vs the popcount-level kernel
+      n = 6: parity elimination in one wave per replica ([r3], default) vs the popcount-level kernel vs the 64 x 64 in-register inverse of
+             round 1 (PK_RAND_PARITY56=0)
     Same LRP12 steps on the same matrices, different elimination orders: equal step counts, trajectories far inside the band of each other
     and of the oracle's closed form -- on draws from the reference's bounds, log-uniform draws over five decades and two stragglers."""
     import os, subprocess, sys
     root = str(pathlib.Path(__file__).resolve().parents[1])
     res = {}
-    for tag, env in (("default", {}), ("twin", {"PK_WIDE_RAND_EXACT": "2", "PK_RAND_LEVEL6": "1"})):
+    for tag, env in (("default", {}), ("twin", {"PK_WIDE_RAND_EXACT": "2", "PK_RAND_LEVEL6": "1"}), ("third", {"PK_RAND_PARITY56": "0"})):
         f = tmp_path / f"{tag}.npz"
         subprocess.run([sys.executable, "-c", _EXACT_SCRIPT, root, str(f)], check=True, env={**os.environ, **env}, timeout=900)
         res[tag] = np.load(f)
-    a, b = res["default"], res["twin"]
+    a, b, c3 = res["default"], res["twin"], res["third"]
+    assert not c3["st6"].any() and np.abs(a["ns6"][:, 0] - c3["ns6"][:, 0]).max() <= 2
+    assert pm.band_error(a["sol6"], c3["sol6"]) <= 0.05
+    np.testing.assert_allclose(a["m6"], c3["m6"], rtol=1e-6)
     for n in (6, 7, 8):
         assert not a[f"st{n}"].any() and not b[f"st{n}"].any()
         assert np.abs(a[f"ns{n}"][:, 0] - b[f"ns{n}"][:, 0]).max() <= 2 and a[f"ns{n}"][:, 0].max() <= 80, (n, a[f"ns{n}"][:, 0], b[f"ns{n}"][:, 0])
