@@ -58,7 +58,10 @@ hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st) {
 
 // forward sensitivities of randmod n = 6, 7: the parity-eliminated inverse serves eight columns per workgroup (pk_rand_sens.hpp)
 hipError_t launch_rand_sens(const SensArgs& a, hipStream_t st) {
-  if (a.s.n_sites == 6) return launch_rand_sens_one<6>(a, st);
+  // n = 6: one wave per column chunk (8 x 8 lanes, 4 x 4 blocks; 34.7 against 44.5 ms per 1 024 Jacobians on the 256-thread grid, same box).
+  // PK_RAND_SENS6_TB=16 (dev, read once): the 256-thread grid
+  static const int tb6 = [] { const char* v = getenv("PK_RAND_SENS6_TB"); return v ? atoi(v) : 8; }();
+  if (a.s.n_sites == 6) return tb6 == 8 ? launch_rand_sens_one<6, 8>(a, st) : launch_rand_sens_one<6, 16>(a, st);
   if (a.s.n_sites == 7) return launch_rand_sens_one<7>(a, st);
   return hipErrorInvalidValue;
 }

@@ -30,11 +30,12 @@ __host__ __device__ constexpr size_t rand_sens_lds_bytes(int n) {
   return (5 * S * kRandSensKC + 3 * NALL + 4 * NM + NM * kRandSensKC + 24) * sizeof(double);
 }
 
-template <int NB>
-__global__ __launch_bounds__(256) void rand_sens_kernel(const SensArgs SA) {
-  static_assert(NB == 6 || NB == 7, "a 16 x 16 thread grid over the even Schur complement: 2 x 2 blocks (n = 6) or 4 x 4 blocks (n = 7)");
+// TBP: side of the thread grid over the even Schur complement: 16 (256 threads) or 8 (n = 6: ONE wave per column chunk, 4 x 4 blocks per lane)
+template <int NB, int TBP = 16>
+__global__ __launch_bounds__(TBP * TBP) void rand_sens_kernel(const SensArgs SA) {
+  static_assert((NB == 6 || NB == 7) && (TBP == 16 || TBP == 8) && (1 << NB) <= TBP * TBP, "thread grid over the even Schur complement");
   using Tab = ResolventTab<PK_METHOD_LRP12>;
-  constexpr int NALL = 1 << NB, NM = NALL / 2, TB = 16, TS = NM / TB, NT = TB * TB, KC = kRandSensKC, KT = KC - 1, S = NALL + 1;
+  constexpr int NALL = 1 << NB, NM = NALL / 2, TB = TBP, TS = NM / TB, NT = TB * TB, KC = kRandSensKC, KT = KC - 1, S = NALL + 1;
   const SolveArgs& A = SA.s;
   extern __shared__ __align__(16) double lds[];
   const int tid = threadIdx.x, nt = NT;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void rand_sens_kernel(const SensArgs SA) {
   finish(status, nacc, nrej);
 }
 
-template <int NB>
+template <int NB, int TBP = 16>
 static hipError_t launch_rand_sens_one(const SensArgs& a, hipStream_t st) {
   constexpr int KT = kRandSensKC - 1;
   const long long nch = (a.s.P + KT - 1) / KT, nblk = a.s.B * nch;
@@ -365,7 +366,7 @@ static hipError_t launch_rand_sens_one(const SensArgs& a, hipStream_t st) {
   }
   constexpr size_t lds = rand_sens_lds_bytes(NB);
   static_assert(lds <= 64 * 1024, "fits the default dynamic-LDS limit");
-  hipLaunchKernelGGL((rand_sens_kernel<NB>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((rand_sens_kernel<NB, TBP>), dim3((unsigned)nblk), dim3(TBP * TBP), lds, st, a);
   return hipGetLastError();
 }
 
