@@ -234,13 +234,13 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
       //                the popcount levels with the Schur complements in LDS (pk_rand_level.hpp)
       //   0            the n-cube kernel below (approximate factorisation), which stays the path for n >= 9
       static const int exact_env = [] { const char* v = getenv("PK_WIDE_RAND_EXACT"); return v ? atoi(v) : 1; }();
-      if (n_sites == 7 && exact_env == 1 && pk::rand_dense_available(7)) { PK_HIP(c, pk::launch_rand_parity(a, c->stream)); return PK_OK; }
+      if (n_sites == 7 && exact_env == 1 && pk::rand_dense_available(7)) { PK_HIP(c, pk::launch_rand_parity(a, c->stream, o.kernel != PK_KERNEL_AUTO)); return PK_OK; }
       if (pk::rand_dense_available(n_sites) && exact_env != 0) {   // n = 7, PK_WIDE_RAND_EXACT=2 (PK_WIDE_RAND_DENSE=0 also selects the n-cube kernel)
         PK_HIP(c, pk::launch_rand_dense(a, c->stream));
         return PK_OK;
       }
       if (n_sites == 8 && exact_env != 0) {
-        PK_HIP(c, exact_env == 2 ? pk::launch_rand_level(a, c->stream) : pk::launch_rand_parity(a, c->stream));
+        PK_HIP(c, exact_env == 2 ? pk::launch_rand_level(a, c->stream) : pk::launch_rand_parity(a, c->stream, o.kernel != PK_KERNEL_AUTO));
         return PK_OK;
       }
       double* scr = nullptr;

@@ -42,9 +42,18 @@ hipError_t launch_rand_level(const SolveArgs& a_in, hipStream_t st) {
 }
 
 // randmod n = 8: odd-popcount states eliminated exactly, the 128 x 128 even Schur complement inverted in registers (pk_rand_parity.hpp)
-hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st) {
+hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st, bool pinned_family) {
   if (a.n_sites == 8) hipLaunchKernelGGL(rand_parity_kernel<8>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(8), st, a);
-  else if (a.n_sites == 7) hipLaunchKernelGGL(rand_parity_kernel<7>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(7), st, a);
+  else if (a.n_sites == 7) {
+    // One wave per replica (8 x 8 lanes, 8 x 8 blocks) at large batches: 386-429 k replicas/s against 336-370 k of the 256-thread grid at
+    // B = 1 024 ... 8 192; below that the grid finishes a launch sooner (1.13-1.30 ms against 2.0-2.3 ms at B = 1 ... 256).  The two sum in
+    // different orders: a caller that pinned the kernel family (opts->kernel, sharded runs that must reproduce one-process bits) keeps
+    // the grid at every size.  PK_RAND_PARITY7_TB=8 / 16 (dev, read once) forces one of them.
+    static const int tb7 = [] { const char* v = getenv("PK_RAND_PARITY7_TB"); return v ? atoi(v) : 0; }();
+    const bool one7 = tb7 == 8 || (tb7 != 16 && !pinned_family && a.B >= 1024);
+    if (one7) hipLaunchKernelGGL((rand_parity_kernel<7, 8>), dim3((unsigned)a.B), dim3(64), rand_parity_lds_bytes(7), st, a);
+    else      hipLaunchKernelGGL((rand_parity_kernel<7, 16>), dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(7), st, a);
+  }
   else if (a.n_sites == 6) {
     // PK_RAND_PARITY6_TB=16 (dev, read once): the 256-thread grid (2 x 2 blocks) instead of one wave per replica (8 x 8 lanes, 4 x 4 blocks)
     static const bool wide6 = [] { const char* v = getenv("PK_RAND_PARITY6_TB"); return v && atoi(v) == 16; }();

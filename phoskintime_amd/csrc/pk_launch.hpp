@@ -39,7 +39,7 @@ hipError_t launch_rand_dense(const SolveArgs&, hipStream_t);
 // randmod n = 8 (and n = 6 on request): LRP12 with exact solves by twisted block elimination over the popcount levels, Schur complements in LDS (pk_rand_level.hpp)
 hipError_t launch_rand_level(const SolveArgs&, hipStream_t);
 // randmod n = 8, the default: LRP12 with exact solves -- odd-popcount states eliminated (diagonal block), even Schur complement inverted in registers (pk_rand_parity.hpp)
-hipError_t launch_rand_parity(const SolveArgs&, hipStream_t);
+hipError_t launch_rand_parity(const SolveArgs&, hipStream_t, bool pinned_family = false);
 bool wide_rand_in_lds(int n_sites);                                         // randmod n >= 7: 9 LDS vectors of 2^n + 1 doubles (n <= 10 / 11)
 size_t wide_rand_scratch_bytes(int n_sites, long long B);                   // 0 when the vectors fit LDS
 hipError_t launch_wide_rand(const SolveArgs&, double* scratch, hipStream_t);   // ROS34PW2-W on the n-cube

@@ -33,7 +33,7 @@ constexpr size_t rand_parity_lds_bytes(int n) {
 // 4 x 4 blocks per lane, every workgroup barrier is a single wave's)
 template <int NB, int TBP = 16>
 __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs A) {
-  static_assert(NB >= 5 && NB <= 8 && (TBP == 16 || TBP == 8) && (1 << NB) <= TBP * TBP, "thread grid over the even Schur complement (one thread per bit mask in the set-up loops)");
+  static_assert(NB >= 5 && NB <= 8 && (TBP == 16 || TBP == 8) && (1 << NB) <= 2 * TBP * TBP, "thread grid over the even Schur complement (at least one thread per even state)");
   constexpr int NALL = 1 << NB;
   using Tab = ResolventTab<PK_METHOD_LRP12>;
   constexpr int NM = NALL / 2, TB = TBP, TS = NM / TB, NT = TB * TB;   // NM even states: the dense core, a TS x TS block per thread
@@ -57,8 +57,7 @@ __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs 
   const double* y0p = A.y0 + (A.y0_batched ? rep * S : 0);
   const double cA = th[0], cB = th[1], cC = th[2];
 
-  if (tid < NALL) {
-    const int m = tid;
+  for (int m = tid; m < NALL; m += nt) {
     if (m == 0) {
       double sumS = 0.0;
       for (int j = 0; j < NB; ++j) sumS += th[4 + j];
@@ -109,8 +108,8 @@ __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs 
     winvR = fast_rcp(__builtin_fma(q, cB, 1.0));
     qC = q * cC;
     {                                                            // the odd states' diagonal, inverted
-      const int c = tid;                                         // 256 threads >= 2^n masks
-      if (c < NALL && (__builtin_popcount(c) & 1)) dio[c] = fast_rcp(__builtin_fma(q, dg[c], 1.0));
+      for (int c = tid; c < NALL; c += nt)
+        if (__builtin_popcount(c) & 1) dio[c] = fast_rcp(__builtin_fma(q, dg[c], 1.0));
     }
     __syncthreads();
     const double q2 = q * q;
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs 
       ++nrej; after_reject = true; h = 0.1 * hs;
       double bad = 0.0;
       for (int row = tid; row < S; row += nt) if (nonfinite(y[row])) bad = 1.0;
-      if (tid < NALL && (nonfinite(dg[tid]) || nonfinite(ci[tid]))) bad = 1.0;
+      for (int m = tid; m < NALL; m += nt) if (nonfinite(dg[m]) || nonfinite(ci[m])) bad = 1.0;
       if (nonfinite(cA) || nonfinite(cB) || nonfinite(cC)) bad = 1.0;
       if (wg_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
       continue;
