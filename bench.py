@@ -592,13 +592,13 @@ def secondary_legs(args, dev, tt, cpu):
         other = {}
         T_ = TGRID.size
         for label, mdl, nn, Bo in (("config1_size_distmod_n4_B65536", "distmod", 4, 65536), ("config2_succmod_n14_B4096", "succmod", 14, 4096),
-                                   ("config2_size_succmod_n14_B65536", "succmod", 14, 65536), ("randmod_n4_B65536", "randmod", 4, 65536),
+                                   ("config2_size_succmod_n14_B65536", "succmod", 14, 65536), ("randmod_n4_B65536", "randmod", 4, 65536), ("randmod_n5_B16384", "randmod", 5, 16384), ("randmod_n6_B16384_one_wave_parity_kernel", "randmod", 6, 16384),
                                    ("wide_distmod_n100_B4096", "distmod", 100, 4096), ("wide_succmod_n100_B4096", "succmod", 100, 4096), ("wide_randmod_n7_B1024", "randmod", 7, 1024), ("wide_randmod_n8_B1024", "randmod", 8, 1024),
                                    ("wide_randmod_n9_B256_ncube_kernel", "randmod", 9, 256)):
             Po, So = batch.n_params(mdl, nn), batch.n_states(mdl, nn)
             tho = torch.as_tensor(np.random.default_rng(20260515).uniform(0.0, 20.0, (Bo, Po)), device=dev)
             oo = batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False)
-            reps = 5 if label.startswith("wide") else 200
+            reps = 5 if label.startswith("wide") else 20 if nn >= 5 and mdl == "randmod" else 200
             for _ in range(max(1, reps // 4)):
                 batch.solve_ode_batch(mdl, tho, np.ones(So), nn, tt, want_flat=False, out=oo)
             torch.cuda.synchronize(dev)
