@@ -43,7 +43,12 @@ hipError_t launch_rand_level(const SolveArgs& a_in, hipStream_t st) {
 
 // randmod n = 8: odd-popcount states eliminated exactly, the 128 x 128 even Schur complement inverted in registers (pk_rand_parity.hpp)
 hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st, bool pinned_family) {
-  if (a.n_sites == 8) hipLaunchKernelGGL(rand_parity_kernel<8>, dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(8), st, a);
+  if (a.n_sites == 8) {
+    // PK_RAND_PARITY8_GRID=512 (dev, read once): the 16 x 32 thread grid (8 x 4 blocks per thread) instead of 16 x 16 (8 x 8 blocks)
+    static const int grid8 = [] { const char* v = getenv("PK_RAND_PARITY8_GRID"); return v ? atoi(v) : 256; }();
+    if (grid8 == 512) hipLaunchKernelGGL((rand_parity_kernel<8, 16, 32>), dim3((unsigned)a.B), dim3(512), rand_parity_lds_bytes(8), st, a);
+    else              hipLaunchKernelGGL((rand_parity_kernel<8, 16, 16>), dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(8), st, a);
+  }
   else if (a.n_sites == 7) {
     // One wave per replica (8 x 8 lanes, 8 x 8 blocks) at large batches: 386-429 k replicas/s against 336-370 k of the 256-thread grid at
     // B = 1 024 ... 8 192; below that the grid finishes a launch sooner (1.13-1.30 ms against 2.0-2.3 ms at B = 1 ... 256).  The two sum in

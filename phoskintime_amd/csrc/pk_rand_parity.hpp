@@ -31,15 +31,19 @@ constexpr size_t rand_parity_lds_bytes(int n) {
 
 // TBP: side of the thread grid over the even Schur complement.  16 (256 threads: n = 7, 8) or 8 (64 threads = ONE wave per replica: n = 6,
 // 4 x 4 blocks per lane, every workgroup barrier is a single wave's)
-template <int NB, int TBP = 16>
-__global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs A) {
-  static_assert(NB >= 5 && NB <= 8 && (TBP == 16 || TBP == 8) && (1 << NB) <= 2 * TBP * TBP, "thread grid over the even Schur complement (at least one thread per even state)");
+// TBJ: columns of the thread grid (default: square).  16 x 32 = 512 threads at n = 8: an 8 x 4 block per thread -- 64 VGPRs of matrix instead
+// of 128, no AGPR traffic, and two workgroups fit a CU.
+template <int NB, int TBP = 16, int TBJ = TBP>
+__global__ __launch_bounds__(TBP * TBJ) void rand_parity_kernel(const SolveArgs A) {
+  static_assert(NB >= 5 && NB <= 8 && (TBP == 16 || TBP == 8) && (TBJ == TBP || TBJ == 2 * TBP) && (1 << NB) <= 2 * TBP * TBJ,
+                "thread grid over the even Schur complement (at least one thread per even state)");
   constexpr int NALL = 1 << NB;
   using Tab = ResolventTab<PK_METHOD_LRP12>;
-  constexpr int NM = NALL / 2, TB = TBP, TS = NM / TB, NT = TB * TB;   // NM even states: the dense core, a TS x TS block per thread
+  constexpr int NM = NALL / 2, TB = TBP, TS = NM / TB, TJ = TBJ, SJ = NM / TJ, NT = TB * TJ;   // NM even states: a TS x SJ block per thread
+  constexpr int CPB = TS / SJ;                                                                // column blocks per row block (1 or 2)
   extern __shared__ __align__(16) double lds[];
   const int tid = threadIdx.x, nt = NT;
-  const int bi = tid / TB, bj = tid % TB, lane = tid & 63;
+  const int bi = tid / TJ, bj = tid % TJ, lane = tid & 63;
   const int n = NB, S = A.S, T = A.T;
   const long long rep = blockIdx.x;
   if (rep >= A.B) return;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs 
   };
 
   // ---- S_ee^-1 in registers: block (bi, bj) = even rows TS bi .. TS bi + TS - 1, even columns TS bj .. TS bj + TS - 1
-  double a[TS][TS], winvR = 1.0, qC = 0.0;
+  double a[TS][SJ], winvR = 1.0, qC = 0.0;
   auto factor = [&](const double q) {
     winvR = fast_rcp(__builtin_fma(q, cB, 1.0));
     qC = q * cC;
@@ -116,9 +120,9 @@ __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs 
     static_for<TS>([&](auto ic) {
       constexpr int ii = decltype(ic)::value;
       const int ma = emask(TS * bi + ii);
-      static_for<TS>([&](auto jc) {
+      static_for<SJ>([&](auto jc) {
         constexpr int jj = decltype(jc)::value;
-        const int mb = emask(TS * bj + jj), d = ma ^ mb;
+        const int mb = emask(SJ * bj + jj), d = ma ^ mb;
         double v = 0.0;
         if (d == 0) {
           double s = 0.0;
@@ -138,29 +142,30 @@ __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs 
     });
 #pragma unroll 1
     for (int kb = 0; kb < TB; ++kb) {
-      const bool prow = (bi == kb), pcol = (bj == kb);
+      const bool prow = (bi == kb);
       static_for<TS>([&](auto kc) {
-        constexpr int kk = decltype(kc)::value;
+        constexpr int kk = decltype(kc)::value;                  // local row of the pivot
+        constexpr int kc_ = kk % SJ;                             // its local column, in column block CPB kb + kk / SJ
         constexpr int p = kk & 1;
-        const int k = TS * kb + kk;
+        const bool pcol = (bj == CPB * kb + kk / SJ);
         double* rb = rowb + p * NM; double* cb = colb + p * NM;
         // [r3] the published pivot row / column are stored TRANSPOSED (entry jj of block bj at [jj][bj]): the lanes of a wave then read 16
         // consecutive doubles per entry.  In block order ([bj][jj], 64 B between the blocks) the sixteen distinct addresses of a read fell
         // on two 16-byte bank groups -- 8-way conflicts on every one of the 8 + 8 reads of a pivot, 2 100 clocks per pivot for 450 of issue
-        if (prow) static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[jj * TB + bj] = a[kk][jj]; });
-        if (pcol) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[ii * TB + bi] = a[ii][kk]; });
+        if (prow) static_for<SJ>([&](auto jc) { constexpr int jj = decltype(jc)::value; rb[jj * TJ + bj] = a[kk][jj]; });
+        if (pcol) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; cb[ii * TB + bi] = a[ii][kc_]; });
         __syncthreads();
-        const double rp = fast_rcp(rb[kk * TB + kb]);
-        double rowv[TS], ml[TS];
-        static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[jj * TB + bj]; });
+        const double rp = fast_rcp(rb[kc_ * TJ + CPB * kb + kk / SJ]);
+        double rowv[SJ], ml[TS];
+        static_for<SJ>([&](auto jc) { constexpr int jj = decltype(jc)::value; rowv[jj] = rb[jj * TJ + bj]; });
         static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; ml[ii] = cb[ii * TB + bi] * rp; });
         static_for<TS>([&](auto ic) {
           constexpr int ii = decltype(ic)::value;
-          static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; a[ii][jj] = __builtin_fma(-ml[ii], rowv[jj], a[ii][jj]); });
+          static_for<SJ>([&](auto jc) { constexpr int jj = decltype(jc)::value; a[ii][jj] = __builtin_fma(-ml[ii], rowv[jj], a[ii][jj]); });
         });
-        if (pcol) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; a[ii][kk] = -ml[ii]; });                 // pivot column: -a_ik / a_kk
-        if (prow) static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; a[kk][jj] = rowv[jj] * rp; });          // pivot row: a_kj / a_kk
-        if (prow && pcol) a[kk][kk] = rp;                                                                                     // pivot: 1 / a_kk
+        if (pcol) static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; a[ii][kc_] = -ml[ii]; });               // pivot column: -a_ik / a_kk
+        if (prow) static_for<SJ>([&](auto jc) { constexpr int jj = decltype(jc)::value; a[kk][jj] = rowv[jj] * rp; });          // pivot row: a_kj / a_kk
+        if (prow && pcol) a[kk][kc_] = rp;                                                                                    // pivot: 1 / a_kk
       });
     }
   };
@@ -175,16 +180,16 @@ __global__ __launch_bounds__(TBP * TBP) void rand_parity_kernel(const SolveArgs 
       for (int j = 0; j < NB; ++j) { const int bit = 1 << j, c = ma ^ bit; s = __builtin_fma(wgt(ma, bit) * dio[c], src[1 + c], s); }
       double r0 = src[1 + ma];
       if (ma == 0) r0 = __builtin_fma(qC, zR, r0);               // the -q C z_R coupling of the mask-0 row moved to the right-hand side
-      re[(tid % TS) * TB + tid / TS] = __builtin_fma(q, s, r0);      // transposed like the pivot buffers: conflict-free reads below
+      re[(tid % SJ) * TJ + tid / SJ] = __builtin_fma(q, s, r0);      // transposed like the pivot buffers: conflict-free reads below
     }
     __syncthreads();
-    double r[TS], pr[TS];
-    static_for<TS>([&](auto jc) { constexpr int jj = decltype(jc)::value; r[jj] = re[jj * TB + bj]; });
+    double r[SJ], pr[TS];
+    static_for<SJ>([&](auto jc) { constexpr int jj = decltype(jc)::value; r[jj] = re[jj * TJ + bj]; });
     static_for<TS>([&](auto ic) {
       constexpr int ii = decltype(ic)::value;
       double v = a[ii][0] * r[0];
-      static_for<TS - 1>([&](auto jc) { constexpr int jj = 1 + decltype(jc)::value; v = __builtin_fma(a[ii][jj], r[jj], v); });
-      pr[ii] = gsum<TB>(v, lane);
+      static_for<SJ - 1>([&](auto jc) { constexpr int jj = 1 + decltype(jc)::value; v = __builtin_fma(a[ii][jj], r[jj], v); });
+      pr[ii] = gsum<TJ>(v, lane);
     });
     static_for<TS>([&](auto ic) { constexpr int ii = decltype(ic)::value; if (bj == ii) dst[1 + emask(TS * bi + ii)] = pr[ii]; });
     __syncthreads();
