@@ -48,8 +48,8 @@ def algorithmic_flops_per_step_model(model: str, n: int) -> float:
       distmod   arrow elimination: `algorithmic_flops_per_step`
       succmod   Thomas on the (n + 2)-row chain: rhs 5n + 6, scaling S, factorisation 5n + 8, twelve solves 12 (5n + 6), accumulation 46 S, norm 6 S
       randmod   2^n cube states (NM) + mRNA: rhs (2n + 2) NM; twelve solves + the inverse they use --
-                n <= 6: dense NM x NM inverse (Gauss-Jordan 2 NM^3) and 2 NM^2 per solve;
-                n = 7, 8: parity elimination (csrc/pk_rand_parity.hpp): NE = NM / 2 even states: fill NE (3n + 4 C(n,2)), inverse 2 NE^3,
+                n <= 5: dense NM x NM inverse (Gauss-Jordan 2 NM^3) and 2 NM^2 per solve;
+                n = 6, 7, 8: parity elimination (csrc/pk_rand_parity.hpp): NE = NM / 2 even states: fill NE (3n + 4 C(n,2)), inverse 2 NE^3,
                 per solve 2 NE^2 + 4 n NM for the two sparse sweeps;  accumulation 46 S, norm 6 S"""
     if model == "distmod":
         return float(algorithmic_flops_per_step(n))
@@ -59,7 +59,7 @@ def algorithmic_flops_per_step_model(model: str, n: int) -> float:
     NM = 1 << n
     S = NM + 1
     base = (2 * n + 2) * NM + 52 * S
-    if n <= 6:
+    if n <= 5:
         return float(base + 2 * NM ** 3 + 12 * 2 * NM ** 2)
     NE = NM // 2
     return float(base + NE * (3 * n + 4 * (n * (n - 1) // 2)) + 2 * NE ** 3 + 12 * (2 * NE ** 2 + 4 * n * NM))
