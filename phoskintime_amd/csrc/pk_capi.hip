@@ -275,7 +275,8 @@ int pk_solve_protein_batch(pk_ctx* c, int model, int n_sites, int64_t B, const d
   }
   // [r3] randmod n = 6 with the default method: parity elimination in ONE wave per replica (pk_rand_parity.hpp, 8 x 8 lanes over the 32 x 32
   // even Schur complement): 2.1-2.2 M replicas/s against 0.59 M of the 64 x 64 in-register inverse below (same box, B = 16 384 ... 65 536).
-  // PK_RAND_PARITY56 (read once): 0 = the old kernel, 1 = also n = 5, one wave per replica (dev: slower there, 5.2-5.8 M against 8.3-9.4 M of the 32-lane kernel)
+  // PK_RAND_PARITY56 (read once): 0 = the old kernel, 1 = also n = 5 (dev; 4 x 4 lanes per replica, four replicas per wave: 9.1-10.2 M against 8.2-9.4 M of the 32-lane kernel at B >= 16 384,
+  // but 0.63 against 0.44 ms per launch at B = 7 -- not worth a second default; one wave per replica: 5.2-5.8 M)
   static const int parity56_env = [] { const char* v = getenv("PK_RAND_PARITY56"); return v ? atoi(v) : -1; }();
   if (model == PK_MODEL_RAND && ((n_sites == 6 && parity56_env != 0) || (n_sites == 5 && parity56_env == 1)) && o.method == PK_METHOD_LRP12 &&
       o.linsolve == PK_LINSOLVE_AUTO && !o.stage_form) {

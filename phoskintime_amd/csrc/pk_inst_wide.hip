@@ -65,7 +65,8 @@ hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st, bool pinned_fa
     if (wide6) hipLaunchKernelGGL((rand_parity_kernel<6, 16>), dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(6), st, a);
     else       hipLaunchKernelGGL((rand_parity_kernel<6, 8>), dim3((unsigned)a.B), dim3(64), rand_parity_lds_bytes(6), st, a);
   }
-  else if (a.n_sites == 5) hipLaunchKernelGGL((rand_parity_kernel<5, 8>), dim3((unsigned)a.B), dim3(64), rand_parity_lds_bytes(5), st, a);
+  else if (a.n_sites == 5)      // 4 x 4 lanes per replica, four replicas per wave
+    hipLaunchKernelGGL((rand_parity_kernel<5, 4>), dim3((unsigned)((a.B + 3) / 4)), dim3(64), 4 * rand_parity_lds_bytes(5), st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -33,20 +33,24 @@ constexpr size_t rand_parity_lds_bytes(int n) {
 // 4 x 4 blocks per lane, every workgroup barrier is a single wave's)
 // TBJ: columns of the thread grid (default: square).  16 x 32 = 512 threads at n = 8: an 8 x 4 block per thread -- 64 VGPRs of matrix instead
 // of 128, no AGPR traffic, and two workgroups fit a CU.
+// A grid of fewer than 64 threads (4 x 4 at n = 5) shares its wave with 64 / (TBP TBJ) - 1 other replicas: one wave per workgroup, every
+// per-replica quantity (LDS region, reductions, outputs) is the group's; the replicas of a wave diverge in their step loops like lanes do.
 template <int NB, int TBP = 16, int TBJ = TBP>
-__global__ __launch_bounds__(TBP * TBJ) void rand_parity_kernel(const SolveArgs A) {
-  static_assert(NB >= 5 && NB <= 8 && (TBP == 16 || TBP == 8) && (TBJ == TBP || TBJ == 2 * TBP) && (1 << NB) <= 2 * TBP * TBJ,
+__global__ __launch_bounds__(TBP * TBJ < 64 ? 64 : TBP * TBJ) void rand_parity_kernel(const SolveArgs A) {
+  static_assert(NB >= 5 && NB <= 8 && (TBP == 16 || TBP == 8 || TBP == 4) && (TBJ == TBP || TBJ == 2 * TBP) && (1 << NB) <= 2 * TBP * TBJ,
                 "thread grid over the even Schur complement (at least one thread per even state)");
   constexpr int NALL = 1 << NB;
   using Tab = ResolventTab<PK_METHOD_LRP12>;
   constexpr int NM = NALL / 2, TB = TBP, TS = NM / TB, TJ = TBJ, SJ = NM / TJ, NT = TB * TJ;   // NM even states: a TS x SJ block per thread
   constexpr int CPB = TS / SJ;                                                                // column blocks per row block (1 or 2)
-  extern __shared__ __align__(16) double lds[];
-  const int tid = threadIdx.x, nt = NT;
-  const int bi = tid / TJ, bj = tid % TJ, lane = tid & 63;
+  constexpr int RPB = NT < 64 ? 64 / NT : 1;                   // replicas per workgroup (> 1: one wave, aligned lane groups)
+  extern __shared__ __align__(16) double lds_all[];
+  const int tid = RPB > 1 ? (int)threadIdx.x % NT : (int)threadIdx.x, nt = NT;
+  const int bi = tid / TJ, bj = tid % TJ, lane = threadIdx.x & 63;
   const int n = NB, S = A.S, T = A.T;
-  const long long rep = blockIdx.x;
+  const long long rep = RPB > 1 ? (long long)blockIdx.x * RPB + threadIdx.x / NT : (long long)blockIdx.x;
   if (rep >= A.B) return;
+  double* lds = lds_all + (RPB > 1 ? (threadIdx.x / NT) * (rand_parity_lds_bytes(NB) / sizeof(double)) : 0);
   const double* __restrict__ th = A.theta + rep * A.P;
   double* y = lds;               double* yn = y + S;          double* u6 = yn + S;
   double* zs = u6 + S;           double* zd = zs + S;                                   // stage vector: source / destination of a solve
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(TBP * TBJ) void rand_parity_kernel(const SolveArgs 
   }
   for (int row = tid; row < S; row += nt) y[row] = y0p[row];
   __syncthreads();
-  WideOut out(A, rep, y0p, prevv, red);
+  WideOut out = RPB > 1 ? WideOut(A, rep, y0p, prevv, red, tid, nt) : WideOut(A, rep, y0p, prevv, red);
+  auto rmax = [&](double v) __attribute__((always_inline)) { if constexpr (RPB > 1) return grp_max(v, nt); else return wg_max(v, red); };
   out.emit(0, y, false);
   int status = PK_ST_OK, nacc = 0, nrej = 0;
   if (T < 2) { out.finish(status, 0, 0); return; }
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(TBP * TBJ) void rand_parity_kernel(const SolveArgs 
     auto mx = [](double p, double r) { return (p > r || p != p) ? p : r; };
     double m = 0.0;
     for (int row = tid; row < S; row += nt) m = mx(m, fabs(e[row]) / __builtin_fma(rtol, fmax(fabs(ya[row]), fabs(yb[row])), atol));
-    return wg_max(m, red);
+    return rmax(m);
   };
 
   // ---- S_ee^-1 in registers: block (bi, bj) = even rows TS bi .. TS bi + TS - 1, even columns TS bj .. TS bj + TS - 1
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(TBP * TBJ) void rand_parity_kernel(const SolveArgs 
       for (int row = tid; row < S; row += nt) if (nonfinite(y[row])) bad = 1.0;
       for (int m = tid; m < NALL; m += nt) if (nonfinite(dg[m]) || nonfinite(ci[m])) bad = 1.0;
       if (nonfinite(cA) || nonfinite(cB) || nonfinite(cC)) bad = 1.0;
-      if (wg_max(bad, red) != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
+      if (rmax(bad) != 0.0) { status |= PK_ST_NONFINITE; fail_from(k); break; }
       continue;
     }
     double fac = root_q(err, Tab::Q) * (1.0 / 0.9);

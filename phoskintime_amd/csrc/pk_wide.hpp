@@ -59,11 +59,24 @@ __device__ __forceinline__ double wg_sum(double v, double* red) {
   return r;
 }
 
-// ---- outputs of one replica owned by a whole workgroup
+// sums / maxima over an aligned group of gnt < 64 lanes of one wave (several replicas per wave: pk_rand_parity.hpp at n = 5)
+__device__ __forceinline__ double grp_sum(double v, const int gnt) { for (int off = gnt >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+__device__ __forceinline__ double grp_max(double v, const int gnt) {
+  auto mx = [](double a, double b) { return (a > b || a != a) ? a : b; };
+  for (int off = gnt >> 1; off > 0; off >>= 1) v = mx(v, __shfl_xor(v, off));
+  return v;
+}
+
+// ---- outputs of one replica owned by a whole workgroup (or, gnt < 64, by an aligned group of gnt lanes: gtid = lane within the group)
 struct WideOut {
   const SolveArgs& A; long long rep; const double* y0p; double* prevv; double* red;     // prevv: LDS [2 + n_obs]
   double s1 = 0.0, s2 = 0.0, dyn = 0.0, shift = 0.0;
-  __device__ __forceinline__ WideOut(const SolveArgs& a, long long r, const double* y0, double* pv, double* rd) : A(a), rep(r), y0p(y0), prevv(pv), red(rd) {}
+  int gtid, gnt; bool grp;
+  __device__ __forceinline__ WideOut(const SolveArgs& a, long long r, const double* y0, double* pv, double* rd) : A(a), rep(r), y0p(y0), prevv(pv), red(rd),
+      gtid(threadIdx.x), gnt(blockDim.x), grp(false) {}
+  __device__ __forceinline__ WideOut(const SolveArgs& a, long long r, const double* y0, double* pv, double* rd, int gt, int gn) : A(a), rep(r), y0p(y0), prevv(pv),
+      red(rd), gtid(gt), gnt(gn), grp(true) {}
+  __device__ __forceinline__ double rsum(double v) { return grp ? grp_sum(v, gnt) : wg_sum(v, red); }
   __device__ __forceinline__ double val(double x, int row, bool nan_fill) const {
     if (nan_fill) return __builtin_nan("");
     double v = A.clip ? ((x < 0.0) ? 0.0 : x) : x;
@@ -72,14 +85,14 @@ struct WideOut {
   }
   // y: vector of S state values (LDS or global); every thread of the block calls
   __device__ __forceinline__ void emit(int k, const double* y, bool nan_fill) {
-    const int tid = threadIdx.x, nt = blockDim.x, S = A.S, T = A.T, nobs = 2 + A.n_obs;
+    const int tid = gtid, nt = gnt, S = A.S, T = A.T, nobs = 2 + A.n_obs;
     const int T5 = T > 5 ? T - 5 : 0;
     double* solp = A.sol ? A.sol + (rep * T + k) * S : nullptr;
     double* fl = A.flat ? A.flat + rep * A.F : nullptr;
     if (A.metric && k == 0) {
       double loc = 0.0;
       for (int row = tid; row < nobs; row += nt) loc += val(y[row], row, nan_fill);
-      shift = wg_sum(loc, red) / nobs;
+      shift = rsum(loc) / nobs;
     }
     for (int row = tid; row < S; row += nt) {
       const double v = val(y[row], row, nan_fill);
@@ -100,18 +113,18 @@ struct WideOut {
   __device__ __forceinline__ void finish(int status, int acc, int rej) {
     if (A.metric) {
       const double L = 2.0 * A.T + (double)A.T * A.n_obs;
-      const double tot = wg_sum(s1, red);
+      const double tot = rsum(s1);
       double m;
       switch (A.metric_id) {
         case PK_METRIC_TOTAL_SIGNAL: m = tot; break;
         case PK_METRIC_MEAN_ACTIVITY: m = tot / L; break;
-        case PK_METRIC_VARIANCE: { const double q = wg_sum(s2, red); const double ms = tot / L - shift; m = q / L - ms * ms; } break;
-        case PK_METRIC_DYNAMICS: m = wg_sum(dyn, red); break;
-        default: { const double q = wg_sum(s2, red); m = sqrt(fmax(q + 2.0 * shift * tot - L * shift * shift, 0.0)); } break;
+        case PK_METRIC_VARIANCE: { const double q = rsum(s2); const double ms = tot / L - shift; m = q / L - ms * ms; } break;
+        case PK_METRIC_DYNAMICS: m = rsum(dyn); break;
+        default: { const double q = rsum(s2); m = sqrt(fmax(q + 2.0 * shift * tot - L * shift * shift, 0.0)); } break;
       }
-      if (threadIdx.x == 0) A.metric[rep] = m;
+      if (gtid == 0) A.metric[rep] = m;
     }
-    if (threadIdx.x == 0) {
+    if (gtid == 0) {
       if (A.status) A.status[rep] = status;
       if (A.n_steps) { A.n_steps[2 * rep] = acc; A.n_steps[2 * rep + 1] = rej; }
     }
