@@ -61,7 +61,9 @@ hipError_t launch_rand_parity(const SolveArgs& a, hipStream_t st, bool pinned_fa
   }
   else if (a.n_sites == 6) {
     // PK_RAND_PARITY6_TB=16 (dev, read once): the 256-thread grid (2 x 2 blocks) instead of one wave per replica (8 x 8 lanes, 4 x 4 blocks)
-    static const bool wide6 = [] { const char* v = getenv("PK_RAND_PARITY6_TB"); return v && atoi(v) == 16; }();
+    static const int tb6 = [] { const char* v = getenv("PK_RAND_PARITY6_TB"); return v ? atoi(v) : 8; }();
+    const bool wide6 = tb6 == 16;
+    // (measured and dropped: 4 x 8 lanes per replica, two replicas per wave -- 1.64-1.68 M replicas/s against 2.09-2.19 M)
     if (wide6) hipLaunchKernelGGL((rand_parity_kernel<6, 16>), dim3((unsigned)a.B), dim3(256), rand_parity_lds_bytes(6), st, a);
     else       hipLaunchKernelGGL((rand_parity_kernel<6, 8>), dim3((unsigned)a.B), dim3(64), rand_parity_lds_bytes(6), st, a);
   }
