@@ -762,7 +762,7 @@ def test_large_network_population_against_reference_runs(f):
     ref_own = band(g["Y_lsoda8"][1], q["Y_tight"][0])           # candidate 0 is the fixture's second parameter set: the reference's own 1e-8 run
     print(f"{f.name}: {K} candidates, default {np.round(e_o, 3).tolist()} in {no[:, 0].cpu().numpy().tolist()} steps | ROS34PW2 {np.round(e_p, 3).tolist()} | "
           f"default at 1e-10 {np.round(e_t, 4).tolist()} | reference LSODA 1e-8 on candidate 0: {ref_own:.3f}")
-    assert max(e_o) <= 0.15 and max(e_p) <= 0.15 and max(e_t) <= 0.01      # measured: <= 0.073, <= 0.077, <= 0.001
+    assert max(e_o) <= 0.15 and max(e_p) <= 0.15 and max(e_t) <= 0.01      # measured over all 28 candidates: <= 0.116, <= 0.080, <= 0.001
     assert e_o[0] <= max(0.1, ref_own)
     if eng.ark_eligible():
         assert (3 * no[:, 0].cpu().numpy() <= 2 * npp[:, 0].cpu().numpy()).all()             # >= 1.5x fewer steps on every candidate (measured 1.7-3.7x)
