@@ -425,6 +425,7 @@ int pk_network_simulate_objective_batch(pk_ctx* c, pk_net* n, pk_loss* l, int64_
                                         const double* defaults, const double* lambdas, double fail_value, double* Y, int32_t* status,
                                         int32_t* n_steps, double* loss_sums, double* F) {
   if (!c || !n || !l) return PK_ERR_ARG;
+  if (B == 0) return PK_OK;
   if (!loss_sums && !F) return pk_ctx_fail(c, PK_ERR_ARG, "null pointer");
   if (F && !lambdas) return pk_ctx_fail(c, PK_ERR_ARG, "lambdas (protein, rna, phospho, prior) are required for F");
   if (loss_mode < 0 || loss_mode > 7) return pk_ctx_fail(c, PK_ERR_ARG, "loss_mode must be 0..7");

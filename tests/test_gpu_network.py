@@ -964,3 +964,33 @@ def test_dense_lane_layout_takes_networks_beyond_256_proteins():
         assert band <= 0.2, band
         assert (3 * na[:, 0].cpu().numpy() <= nr[:, 0].cpu().numpy()).all()
         eng.close()
+
+
+def test_fused_objective_edge_shapes():
+    """One candidate, the shortest grids: T = 1 (only the initial time: every fold change is 1) and T = 2; an empty batch."""
+    import torch
+    from phoskintime_amd.global_model import NetworkEngine
+    g = np.load(Path(__file__).resolve().parent / "golden" / "network_m0_small.npz")
+    eng = NetworkEngine.from_npz(g)
+    X = _x(eng, g, 0)[None, :]
+    for t in (np.array([0.0]), np.array([0.0, 7.5])):
+        lists, ld = eng.make_index_lists(t, t, t[-1:], t)                # rna from its baseline on (the baseline is the grid point nearest t = 4)
+        eng.free_loss(lists)
+        rng = np.random.default_rng(0)
+        for k in ("obs_prot", "obs_rna", "obs_pho"):
+            ld[k] = rng.uniform(0.5, 1.5, ld[k].size)
+        loss = eng.make_loss(ld, t.size)
+        Y, st, ns = eng.simulate_batch(X, t, rtol=1e-8, atol=1e-8)
+        s2, F2 = eng.objective_batch(loss, Y, x=X, defaults=X[0], lambdas=(1.0, 1.0, 1.0, 0.5), status=st)
+        out = eng.simulate_objective_batch(loss, X, t, rtol=1e-8, atol=1e-8, defaults=X[0], lambdas=(1.0, 1.0, 1.0, 0.5))
+        assert out is not None
+        np.testing.assert_allclose(out[0].cpu().numpy(), s2.cpu().numpy(), rtol=1e-12)
+        np.testing.assert_allclose(out[1].cpu().numpy(), F2.cpu().numpy(), rtol=1e-12)
+        if t.size == 1:                                                   # pred = 1 everywhere: the sums are the weighted squared distances of the observations from 1
+            want = [float(np.sum(ld["w_" + m] * (ld["obs_" + m] - 1.0) ** 2)) for m in ("prot", "rna", "pho")]
+            assert ld["rna_base_idx"] == 0
+            np.testing.assert_allclose(out[0].cpu().numpy()[0], want, rtol=1e-12)
+        empty = eng.simulate_objective_batch(loss, np.zeros((0, eng.n_var)), t, rtol=1e-8, atol=1e-8)
+        assert empty is not None and empty[1].shape == (0, 3)
+        eng.free_loss(loss)
+    eng.close()
